@@ -1,0 +1,126 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own classes.
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+Each fixture holds plain arrays: the reference module's state_dict
+(``param/<name>``), the inputs (``in/<k>``), labels ``y``, the forward output
+``prob``, ``torch.nn.BCELoss`` value ``loss`` and the gradient of every
+parameter after ``loss.backward()`` (``grad/<name>``) -- i.e. one
+``Trainer.train_loop`` body (trainer/trainer.py:30-38) without the optimizer.
+Nothing of the reference's source is stored.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = os.environ.get("CTR_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+sys.path.insert(0, REFERENCE)
+
+from deeplearningrecommendationsystem_amd import synth  # noqa: E402
+
+
+def _ref_classes():
+    from model.mf import MatrixFactorization
+    from model.neuralcf import NeuralCF
+    from model.ffm import FFM
+    from model.pnn import PNN
+    from model.deepcrossing import DeepCrossing
+    from model.deepfm import DeepFM
+    from model.din import DIN
+    from model.dien import DIEN
+    return dict(mf=MatrixFactorization, neuralcf=NeuralCF, ffm=FFM, pnn=PNN,
+                deepcrossing=DeepCrossing, deepfm=DeepFM, din=DIN, dien=DIEN)
+
+
+# name -> (model key, ctor args, ctor kwargs, input builder(gen) -> (inputs, y))
+def _cases():
+    c = {}
+
+    def ids(b, nu, ni, two_d):
+        def f(g):
+            u, i = synth.id_batch(b, nu, ni, g)
+            return [u, i], synth.labels(b, two_d, g)
+        return f
+
+    def feats(b, nu=943, ni=1682, zero_genre=0):
+        def f(g):
+            return [synth.feature_batch(b, nu, ni, g, zero_genre_rows=zero_genre)], synth.labels(b, True, g)
+        return f
+
+    def seq(b, length, ni, pad=0.25):
+        def f(g):
+            h, t = synth.hist_batch(b, length, ni, g, pad_fraction=pad)
+            return [h, t], synth.labels(b, True, g)
+        return f
+
+    for s in (0, 1):
+        c[f"mf_s{s}"] = ("mf", (30, 40, 8), {}, ids(64, 30, 40, False), s)
+        c[f"neuralcf_s{s}"] = ("neuralcf", (30, 40, 8, [16, 8, 4]), {}, ids(64, 30, 40, True), s)
+        c[f"ffm_s{s}"] = ("ffm", (43, 8), {}, feats(64, zero_genre=4), s)
+        c[f"pnn_s{s}"] = ("pnn", (8, [32, 16, 8]), {}, feats(64, zero_genre=4), s)
+        c[f"deepcrossing_s{s}"] = ("deepcrossing", (30, 40, 8, [16, 8]), {}, feats(64, 30, 40, 4), s)
+        c[f"deepfm_s{s}"] = ("deepfm", (30, 40, [32, 16, 1], 8), {}, feats(64, 30, 40, 4), s)
+        c[f"din_s{s}"] = ("din", (50, 8), {}, seq(64, 10, 50), s)
+        c[f"dien_s{s}"] = ("dien", (50, 8), {}, seq(64, 10, 50), s)
+    # edge cases: ragged batch (not a multiple of the wave size), a single
+    # sample, heavy id duplication, L = 1, a long un-truncated history
+    c["mf_b37"] = ("mf", (5, 7, 12), {}, ids(37, 5, 7, False), 2)
+    c["mf_b1"] = ("mf", (5, 7, 4), {}, ids(1, 5, 7, False), 3)
+    c["neuralcf_b37"] = ("neuralcf", (5, 7, 4, [8, 4]), {}, ids(37, 5, 7, True), 2)
+    c["ffm_b37"] = ("ffm", (43, 4), {}, feats(37), 2)
+    c["pnn_b37"] = ("pnn", (4, [16, 8]), {}, feats(37), 2)
+    c["pnn_outer_b8"] = ("pnn", (8, [16, 8]), {"model": "out"}, feats(8), 2)
+    c["deepcrossing_b37"] = ("deepcrossing", (5, 7, 4, [8]), {}, feats(37, 5, 7), 2)
+    c["deepfm_b37"] = ("deepfm", (5, 7, [16, 1], 4), {}, feats(37, 5, 7), 2)
+    c["din_l1"] = ("din", (20, 4), {}, seq(37, 1, 20), 2)
+    c["din_l130"] = ("din", (20, 4), {}, seq(5, 130, 20, pad=0.0), 3)
+    c["din_allpad"] = ("din", (20, 8), {}, seq(16, 6, 20, pad=1.0), 4)
+    c["dien_l1"] = ("dien", (20, 4), {}, seq(37, 1, 20), 2)
+    c["dien_l33"] = ("dien", (20, 4), {}, seq(9, 33, 20), 3)
+    return c
+
+
+def main():
+    out_dir = os.path.join(REPO, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    classes = _ref_classes()
+    torch.set_num_threads(1)  # single-thread accumulation order for the index-add grads
+    total = 0
+    for name, (key, args, kwargs, build, seed) in sorted(_cases().items()):
+        torch.manual_seed(seed)
+        model = classes[key](*args, **kwargs)
+        inputs, y = build(synth.generator(1000 + seed))
+        model.train()
+        prob = model(*inputs)
+        loss = torch.nn.BCELoss()(prob, y)
+        loss.backward()
+        arrays = {"y": y.numpy(), "prob": prob.detach().numpy(), "loss": loss.detach().numpy()}
+        for k, t in enumerate(inputs):
+            arrays[f"in/{k}"] = t.numpy()
+        for pname, pt in model.state_dict().items():
+            arrays[f"param/{pname}"] = pt.detach().numpy()
+        for pname, pt in model.named_parameters():
+            g = pt.grad if pt.grad is not None else torch.zeros_like(pt)
+            arrays[f"grad/{pname}"] = g.numpy()
+        meta = {"model": key, "args": list(args), "kwargs": kwargs, "seed": seed,
+                "torch": torch.__version__}
+        arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        path = os.path.join(out_dir, name + ".npz")
+        np.savez_compressed(path, **arrays)
+        total += os.path.getsize(path)
+        print(f"{name:24s} loss={loss.item():.6f} {os.path.getsize(path) / 1024:.1f} KiB")
+    print(f"total {total / 1024:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()
