@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CTR samples/s, forward+backward, batch 65536 per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload neuralcf]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one Trainer.train_loop body without the optimizer (reference
+trainer/trainer.py:24-38): zero_grad, model forward, BCELoss, backward -- on
+synthetic ml-100k-shaped ids already resident in HBM.  With N > 1 every rank
+runs its own batch of 65536 (weak scaling) and the replicated parameters'
+gradients are averaged with one RCCL all-reduce inside the step.
+
+Prints ONE JSON line (rank 0) with the contract keys plus
+  roofline      dominant kernel of the step (by measured time), HIP events on the launch stream
+  cpu_baseline  the CPU oracle (oracle/ctr_oracle.py) timed on this box's host cores
+  kernels       per-kernel breakdown of one step; gather_roofline = the embedding-stage kernel
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+F32_MFMA_PEAK_TF = 157.3    # dense fp32 matrix peak
+BATCH = 65536
+
+
+def build_workload(name: str, device, rank: int):
+    from deeplearningrecommendationsystem_amd import synth
+    from deeplearningrecommendationsystem_amd import model as zoo
+    gen = synth.generator(1234 + rank)
+    torch.manual_seed(1234)  # identical replicas on every rank
+    if name == "neuralcf":
+        # BASELINE.json configs[1]: model/neuralcf.py, emb_dim 64, batch 65536, ml-100k ids
+        m = zoo.NeuralCF(943, 1682, 64, [128, 64, 32, 16, 8])
+        u, i = synth.id_batch(BATCH, gen=gen)
+        inputs, y = [u, i], synth.labels(BATCH, True, gen)
+        desc = "neuralcf mf_dim=64 layers=[128,64,32,16,8] users=943 items=1682 batch=65536/gpu (BASELINE configs[1])"
+    elif name == "mf":
+        m = zoo.MatrixFactorization(943, 1682, 64)
+        u, i = synth.id_batch(BATCH, gen=gen)
+        inputs, y = [u, i], synth.labels(BATCH, False, gen)
+        desc = "mf emb=64 users=943 items=1682 batch=65536/gpu"
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    return m.to(device), [t.to(device) for t in inputs], y.to(device), desc
+
+
+def cpu_baseline(name: str, model, budget_s: float = 15.0):
+    """time the CPU oracle on the same workload (bounded sample), rank 0 only"""
+    from deeplearningrecommendationsystem_amd import synth
+    from oracle import ctr_oracle as orc  # checker/baseline only, never on the product path
+    threads = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU
+    torch.set_num_threads(threads)
+    params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    gen = synth.generator(1234)
+    u, i = synth.id_batch(BATCH, gen=gen)
+    y = synth.labels(BATCH, name != "mf", gen)
+    orc.step(name, params, [u, i], y)  # warm-up
+    t0 = time.perf_counter()
+    orc.step(name, params, [u, i], y)
+    one = time.perf_counter() - t0
+    reps = max(3, min(200, int(budget_s / max(one, 1e-4))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orc.step(name, params, [u, i], y)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": BATCH / dt, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} fwd+bwd steps of batch {BATCH} through oracle/ctr_oracle.py (torch CPU, fp32)",
+            "ms_per_step": dt * 1e3}
+
+
+def roofline_entry(label, rec):
+    secs = rec["avg_us"] * 1e-6
+    gbs = rec["bytes"] / secs / 1e9
+    tfs = rec["flops"] / secs / 1e12
+    # the bound is whichever roof the launch sits closer to
+    if rec["flops"] and tfs / F32_MFMA_PEAK_TF > gbs / HBM_PEAK_GBS:
+        return {"kernel": label, "bound": "mfma", "achieved": tfs, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": tfs / F32_MFMA_PEAK_TF, "traffic": None, "avg_us": rec["avg_us"],
+                "algorithmic_flops": rec["flops"]}
+    return {"kernel": label, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_us": rec["avg_us"],
+            "algorithmic_bytes": rec["bytes"]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="neuralcf")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)
+
+    from deeplearningrecommendationsystem_amd import ops
+    from deeplearningrecommendationsystem_amd.dist import GradBucket
+
+    model, inputs, y, desc = build_workload(args.workload, device, rank)
+    loss_fn = torch.nn.BCELoss()
+    bucket = GradBucket(model.parameters()) if world > 1 else None
+    model.train()
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        prob = model(*inputs)
+        loss = loss_fn(prob, y)
+        loss.backward()
+        if bucket is not None:
+            bucket.all_reduce_mean()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * BATCH * args.steps / elapsed
+
+    # per-kernel durations: the same steps again with a HIP event pair around every launch
+    prof = ops.KernelProfiler()
+    ops.set_profiler(prof)
+    for _ in range(args.steps):
+        step()
+    ops.set_profiler(None)
+    kernels = prof.summary()
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        entries = {k: roofline_entry(k, v) for k, v in kernels.items()}
+        dominant = max(kernels, key=lambda k: kernels[k]["total_us"])
+        kernel_us = sum(v["total_us"] for v in kernels.values()) / args.steps
+        out = {
+            "metric": "CTR samples/sec fwd+bwd at batch 65536",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "global_batch": world * BATCH,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "loss": float(loss.item()),
+            "roofline": entries[dominant],
+            "gather_roofline": entries.get("embed_fwd"),
+            "kernels": {k: {"avg_us": round(v["avg_us"], 2), "calls_per_step": v["calls"] / args.steps,
+                            "bound": entries[k]["bound"], "frac": round(entries[k]["frac"], 4)}
+                        for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["total_us"])},
+            "gpu_kernel_us_per_step": round(kernel_us, 1),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, model)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,102 @@
+"""ctypes binding of libctrhip.so (the C ABI declared in include/ctrhip.h).
+
+There is no CPU fallback: if the shared library is missing or a tensor is not on
+a HIP device the call raises.  ``import torch`` must happen before the library
+is loaded so that it binds to the HIP runtime PyTorch already mapped (same
+SONAME ``libamdhip64.so.7``) and shares its streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch  # noqa: F401  (maps libamdhip64 first, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libctrhip.so")
+ABI_VERSION = 1
+
+CTR_MAX_FIELDS = 32
+FIELD_ID_I64, FIELD_ID_F32, FIELD_BAG, FIELD_DENSE, FIELD_PROD_I64 = range(5)
+ACT_NONE, ACT_RELU, ACT_SIGMOID = range(3)
+
+
+class Field(C.Structure):
+    """mirror of ``ctr_field_t``"""
+    _fields_ = [
+        ("kind", C.c_int32), ("width", C.c_int32), ("out_col", C.c_int32), ("src_col", C.c_int32),
+        ("bag_size", C.c_int32), ("reserved", C.c_int32),
+        ("vocab", C.c_int64), ("idx_stride", C.c_int64),
+        ("idx", C.c_void_p), ("table", C.c_void_p), ("grad", C.c_void_p),
+        ("idx2", C.c_void_p), ("table2", C.c_void_p), ("grad2", C.c_void_p),
+        ("vocab2", C.c_int64),
+    ]
+
+
+_p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); must list every `ctr_*` symbol of include/ctrhip.h
+SIGNATURES = {
+    "ctr_version": (C.c_int, []),
+    "ctr_strerror": (C.c_char_p, [_i]),
+    "ctr_target_arch": (C.c_char_p, []),
+    "ctr_embed_fwd": (_i, [C.POINTER(Field), _i, _p, _l, _l, _p, _l, _p, _p]),
+    "ctr_embed_bwd": (_i, [C.POINTER(Field), _i, _p, _l, _l, _p, _l, _p]),
+    "ctr_mf_fwd": (_i, [_p, _l, _p, _l, _i, _p, _p, _l, _p, _p, _p]),
+    "ctr_mf_bwd": (_i, [_p, _l, _p, _l, _i, _p, _p, _l, _p, _p, _p, _p, _p]),
+    "ctr_linear_fwd": (_i, [_p, _l, _p, _l, _p, _p, _l, _p, _l, _l, _i, _i, _i, _p]),
+    "ctr_linear_bwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _p, _l, _i, _p, _l, _p, _l, _i, _i, _i, _p]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class CtrHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libctrhip.so once; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise CtrHipError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C deeplearningrecommendationsystem_amd/csrc`). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        got = lib.ctr_version()
+        if got != ABI_VERSION:
+            raise CtrHipError(f"libctrhip ABI version {got}, python binding expects {ABI_VERSION}: rebuild")
+        _lib = lib
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise CtrHipError(f"{what} failed: {load().ctr_strerror(code).decode()} ({code})")
+
+
+def stream_ptr() -> int:
+    """the HIP stream kernels must be enqueued on: torch's current stream"""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise CtrHipError("libctrhip kernels need tensors on a HIP device (got a CPU tensor); "
+                              "this backend has no CPU fallback")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()

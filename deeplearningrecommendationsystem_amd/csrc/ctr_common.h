@@ -1,0 +1,77 @@
+// Shared device/host helpers for libctrhip (gfx950 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ctrhip.h"
+
+#define CTR_WAVE 64
+
+#define CTR_REQUIRE(cond, code) \
+  do {                          \
+    if (!(cond)) return (code); \
+  } while (0)
+
+static inline int ctr_launch_status() { return hipGetLastError() == hipSuccess ? CTR_OK : CTR_ELAUNCH; }
+
+static inline int64_t ctr_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+static inline bool ctr_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// memory-bound grids: enough blocks to fill 256 CUs x 8, grid-stride the rest (guide G11)
+static inline int ctr_stream_grid(int64_t work_items, int per_block) {
+  int64_t g = ctr_ceil_div(work_items, per_block);
+  if (g < 1) g = 1;
+  if (g > 256 * 8) g = 256 * 8;
+  return (int)g;
+}
+
+__device__ __forceinline__ float ctr_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// sum over aligned groups of G lanes (G power of two <= 64)
+template <int G>
+__device__ __forceinline__ float ctr_group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float ctr_sigmoid(float z) { return 1.0f / (1.0f + expf(-z)); }
+
+__device__ __forceinline__ float ctr_act(float z, int act) {
+  if (act == CTR_ACT_RELU) return z > 0.0f ? z : 0.0f;
+  if (act == CTR_ACT_SIGMOID) return ctr_sigmoid(z);
+  return z;
+}
+
+// derivative of the activation expressed through its OUTPUT y
+__device__ __forceinline__ float ctr_act_grad(float y, int act) {
+  if (act == CTR_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
+  if (act == CTR_ACT_SIGMOID) return y * (1.0f - y);
+  return 1.0f;
+}
+
+// Pointers that reach a kernel through an LDS/kernarg descriptor are "generic" to
+// the compiler and lower to flat_* instructions; these helpers assert the global
+// address space so loads/stores/atomics become global_* (vmcnt only).
+#define CTR_GLOBAL __attribute__((address_space(1)))
+typedef float ctr_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float ctr_ldg(const float* p) { return *(const CTR_GLOBAL float*)p; }
+__device__ __forceinline__ int64_t ctr_ldg(const int64_t* p) { return *(const CTR_GLOBAL int64_t*)p; }
+__device__ __forceinline__ float4 ctr_ldg(const float4* p) {
+  const ctr_f32x4 v = *(const CTR_GLOBAL ctr_f32x4*)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void ctr_stg(float* p, float v) { *(CTR_GLOBAL float*)p = v; }
+__device__ __forceinline__ void ctr_stg(float4* p, float4 v) {
+  ctr_f32x4 w;
+  w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+  *(CTR_GLOBAL ctr_f32x4*)p = w;
+}
+__device__ __forceinline__ void ctr_atomic_add_global(float* p, float v) {
+  (void)__builtin_amdgcn_global_atomic_fadd_f32((CTR_GLOBAL float*)p, v);
+}

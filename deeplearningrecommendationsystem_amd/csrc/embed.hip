@@ -1,0 +1,325 @@
+// Embedding stage: fused row gather (K1/K3) + weighted bag pooling (K2) + concat,
+// and its backward (K11).  HBM-bound byte moving: no MFMA here by design.
+//
+// Work decomposition: the output row of one sample is cut into "units" of VEC
+// floats (VEC = 4 -> one dwordx4 per lane).  Consecutive lanes take consecutive
+// units of the flat (sample, unit) space, so every wave-instruction stores 1 KiB
+// contiguous and reads its indices coalesced, whatever the field widths are; a
+// 64-byte table row (E = 16) is fetched by 4 neighbouring lanes, i.e. one
+// wave-instruction has 16 independent rows in flight.
+#include "ctr_common.h"
+
+namespace {
+
+constexpr int kMaxUnits = 2048;   // units per sample the per-block LUT can hold
+constexpr int kBlock = 256;
+
+struct FieldPack {
+  ctr_field_t f[CTR_MAX_FIELDS];
+};
+
+struct UnitLut {
+  ctr_field_t f[CTR_MAX_FIELDS];
+  int start[CTR_MAX_FIELDS + 1];       // first unit of field
+  unsigned short field_of[kMaxUnits];  // unit -> field
+};
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<1> {
+  using T = float;
+  static __device__ __forceinline__ T zero() { return 0.0f; }
+};
+template <>
+struct Vec<4> {
+  using T = float4;
+  static __device__ __forceinline__ T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+};
+
+__device__ __forceinline__ float vfma(float w, float t, float a) { return fmaf(w, t, a); }
+__device__ __forceinline__ float4 vfma(float w, float4 t, float4 a) {
+  return make_float4(fmaf(w, t.x, a.x), fmaf(w, t.y, a.y), fmaf(w, t.z, a.z), fmaf(w, t.w, a.w));
+}
+__device__ __forceinline__ float vmul(float a, float b) { return a * b; }
+__device__ __forceinline__ float4 vmul(float4 a, float4 b) {
+  return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+}
+__device__ __forceinline__ float vscale(float w, float a) { return w * a; }
+__device__ __forceinline__ float4 vscale(float w, float4 a) { return make_float4(w * a.x, w * a.y, w * a.z, w * a.w); }
+
+__device__ __forceinline__ void atomic_add_vec(float* p, float v) { ctr_atomic_add_global(p, v); }
+__device__ __forceinline__ void atomic_add_vec(float* p, float4 v) {
+  ctr_atomic_add_global(p + 0, v.x);
+  ctr_atomic_add_global(p + 1, v.y);
+  ctr_atomic_add_global(p + 2, v.z);
+  ctr_atomic_add_global(p + 3, v.w);
+}
+
+template <int VEC>
+__device__ __forceinline__ void build_lut(UnitLut& s, const FieldPack& P, int nfields) {
+  // descriptors: kernarg -> LDS, one dword per lane
+  const int words = nfields * (int)(sizeof(ctr_field_t) / 4);
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(&P);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(s.f);
+  for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int f = 0; f < nfields; ++f) {
+      s.start[f] = acc;
+      acc += s.f[f].width / VEC;
+    }
+    s.start[nfields] = acc;
+  }
+  __syncthreads();
+  const int upr = s.start[nfields];
+  for (int u = threadIdx.x; u < upr; u += blockDim.x) {
+    int f = 0;
+    while (u >= s.start[f + 1]) ++f;
+    s.field_of[u] = (unsigned short)f;
+  }
+  __syncthreads();
+}
+
+// row index of an id field for sample b; out-of-range -> row 0 + flag
+__device__ __forceinline__ int64_t checked_row(int64_t r, int64_t vocab, int32_t* err_flag) {
+  if (r < 0 || r >= vocab) {
+    if (err_flag) *err_flag = 1;
+    return 0;
+  }
+  return r;
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+embed_fwd_kernel(const FieldPack P, int nfields, const float* __restrict__ x, int64_t ldx, uint32_t batch,
+                 float* __restrict__ out, int64_t ldo, int32_t* err_flag) {
+  using V = typename Vec<VEC>::T;
+  __shared__ UnitLut s;
+  build_lut<VEC>(s, P, nfields);
+  const uint32_t upr = (uint32_t)s.start[nfields];
+  const uint64_t total = (uint64_t)batch * upr;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    const uint32_t b = (uint32_t)(g / upr);
+    const uint32_t u = (uint32_t)(g - (uint64_t)b * upr);
+    const int fi = s.field_of[u];
+    const ctr_field_t& f = s.f[fi];
+    const int off = (int)(u - (uint32_t)s.start[fi]) * VEC;
+    V v;
+    switch (f.kind) {
+      case CTR_FIELD_ID_I64: {
+        const int64_t r = checked_row(ctr_ldg(f.idx + (int64_t)b * f.idx_stride), f.vocab, err_flag);
+        v = ctr_ldg(reinterpret_cast<const V*>(f.table + r * f.width + off));
+      } break;
+      case CTR_FIELD_ID_F32: {
+        const int64_t r = checked_row((int64_t)x[(int64_t)b * ldx + f.src_col], f.vocab, err_flag);
+        v = ctr_ldg(reinterpret_cast<const V*>(f.table + r * f.width + off));
+      } break;
+      case CTR_FIELD_BAG: {
+        // in-order fp32 FMA chain over the K bag rows: a one-hot slice returns
+        // the selected row bit-exactly, as the reference's matmul does
+        const float* xr = x + (int64_t)b * ldx + f.src_col;
+        v = Vec<VEC>::zero();
+        for (int j = 0; j < f.bag_size; ++j)
+          v = vfma(xr[j], ctr_ldg(reinterpret_cast<const V*>(f.table + (int64_t)j * f.width + off)), v);
+      } break;
+      case CTR_FIELD_DENSE: {
+        v = *reinterpret_cast<const V*>(x + (int64_t)b * ldx + f.src_col + off);
+      } break;
+      default: {  // CTR_FIELD_PROD_I64
+        const int64_t r1 = checked_row(ctr_ldg(f.idx + (int64_t)b * f.idx_stride), f.vocab, err_flag);
+        const int64_t r2 = checked_row(ctr_ldg(f.idx2 + (int64_t)b * f.idx_stride), f.vocab2, err_flag);
+        v = vmul(ctr_ldg(reinterpret_cast<const V*>(f.table + r1 * f.width + off)),
+                 ctr_ldg(reinterpret_cast<const V*>(f.table2 + r2 * f.width + off)));
+      } break;
+    }
+    *reinterpret_cast<V*>(out + (int64_t)b * ldo + f.out_col + off) = v;
+  }
+}
+
+// Backward.  Id fields: one fp32 atomic per gradient element straight into the
+// dense (V,E) gradient (rows are spread over a large table, the good case for
+// memory-side atomics).  Bag fields: every sample hits the same <= 21 rows, the
+// worst case for global atomics, so each block first reduces into an LDS copy of
+// the bag tables' gradients (ds_add_f32) and flushes it once.
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+embed_bwd_kernel(const FieldPack P, int nfields, const float* __restrict__ x, int64_t ldx, uint32_t batch,
+                 const float* __restrict__ gout, int64_t ldo, int bag_floats) {
+  using V = typename Vec<VEC>::T;
+  __shared__ UnitLut s;
+  __shared__ int s_bag_off[CTR_MAX_FIELDS];
+  extern __shared__ float s_bag[];  // bag_floats accumulators
+  build_lut<VEC>(s, P, nfields);
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int f = 0; f < nfields; ++f) {
+      s_bag_off[f] = acc;
+      if (s.f[f].kind == CTR_FIELD_BAG && s.f[f].grad) acc += s.f[f].bag_size * s.f[f].width;
+    }
+  }
+  for (int i = threadIdx.x; i < bag_floats; i += blockDim.x) s_bag[i] = 0.0f;
+  __syncthreads();
+
+  const uint32_t upr = (uint32_t)s.start[nfields];
+  const uint64_t total = (uint64_t)batch * upr;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    const uint32_t b = (uint32_t)(g / upr);
+    const uint32_t u = (uint32_t)(g - (uint64_t)b * upr);
+    const int fi = s.field_of[u];
+    const ctr_field_t& f = s.f[fi];
+    if (f.kind == CTR_FIELD_DENSE) continue;
+    const int off = (int)(u - (uint32_t)s.start[fi]) * VEC;
+    const V gv = *reinterpret_cast<const V*>(gout + (int64_t)b * ldo + f.out_col + off);
+    switch (f.kind) {
+      case CTR_FIELD_ID_I64:
+      case CTR_FIELD_ID_F32: {
+        if (!f.grad) break;
+        int64_t r = f.kind == CTR_FIELD_ID_I64 ? ctr_ldg(f.idx + (int64_t)b * f.idx_stride)
+                                                : (int64_t)x[(int64_t)b * ldx + f.src_col];
+        if (r < 0 || r >= f.vocab) r = 0;
+        atomic_add_vec(f.grad + r * f.width + off, gv);
+      } break;
+      case CTR_FIELD_BAG: {
+        if (!f.grad) break;
+        const float* xr = x + (int64_t)b * ldx + f.src_col;
+        float* acc = s_bag + s_bag_off[fi] + off;
+        for (int j = 0; j < f.bag_size; ++j) {
+          const float w = xr[j];
+          if (w != 0.0f) {
+            const V c = vscale(w, gv);
+            const float* cp = reinterpret_cast<const float*>(&c);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) atomicAdd(acc + (int64_t)j * f.width + e, cp[e]);
+          }
+        }
+      } break;
+      default: {  // PROD: d(t1*t2) = g*t2, g*t1
+        int64_t r1 = ctr_ldg(f.idx + (int64_t)b * f.idx_stride);
+        int64_t r2 = ctr_ldg(f.idx2 + (int64_t)b * f.idx_stride);
+        if (r1 < 0 || r1 >= f.vocab) r1 = 0;
+        if (r2 < 0 || r2 >= f.vocab2) r2 = 0;
+        const V t1 = ctr_ldg(reinterpret_cast<const V*>(f.table + r1 * f.width + off));
+        const V t2 = ctr_ldg(reinterpret_cast<const V*>(f.table2 + r2 * f.width + off));
+        if (f.grad) atomic_add_vec(f.grad + r1 * f.width + off, vmul(gv, t2));
+        if (f.grad2) atomic_add_vec(f.grad2 + r2 * f.width + off, vmul(gv, t1));
+      } break;
+    }
+  }
+  __syncthreads();
+  for (int fi = 0; fi < nfields; ++fi) {
+    const ctr_field_t& f = s.f[fi];
+    if (f.kind != CTR_FIELD_BAG || !f.grad) continue;
+    const int n = f.bag_size * f.width;
+    const float* acc = s_bag + s_bag_off[fi];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const float v = acc[i];
+      if (v != 0.0f) ctr_atomic_add_global(f.grad + i, v);
+    }
+  }
+}
+
+struct Plan {
+  FieldPack pack;
+  int vec;
+  int units;
+  int bag_floats;
+};
+
+int make_plan(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, const float* io, int64_t ldo,
+              bool backward, Plan* plan) {
+  CTR_REQUIRE(fields && nfields > 0 && nfields <= CTR_MAX_FIELDS && io, CTR_EINVAL);
+  bool vec4 = ctr_aligned16(io) && (ldo % 4 == 0);
+  int floats = 0, bag_floats = 0;
+  bool needs_x = false;
+  for (int i = 0; i < nfields; ++i) {
+    const ctr_field_t& f = fields[i];
+    CTR_REQUIRE(f.kind >= CTR_FIELD_ID_I64 && f.kind <= CTR_FIELD_PROD_I64, CTR_EINVAL);
+    CTR_REQUIRE(f.width > 0 && f.out_col >= 0 && (int64_t)f.out_col + f.width <= ldo, CTR_EINVAL);
+    if (f.kind != CTR_FIELD_DENSE) {
+      CTR_REQUIRE(f.table && f.vocab > 0, CTR_EINVAL);
+      vec4 = vec4 && ctr_aligned16(f.table);
+    }
+    if (f.kind == CTR_FIELD_ID_I64 || f.kind == CTR_FIELD_PROD_I64) CTR_REQUIRE(f.idx && f.idx_stride >= 0, CTR_EINVAL);
+    if (f.kind == CTR_FIELD_PROD_I64) {
+      CTR_REQUIRE(f.idx2 && f.table2 && f.vocab2 > 0, CTR_EINVAL);
+      vec4 = vec4 && ctr_aligned16(f.table2);
+    }
+    if (f.kind == CTR_FIELD_ID_F32 || f.kind == CTR_FIELD_BAG || f.kind == CTR_FIELD_DENSE) {
+      needs_x = true;
+      CTR_REQUIRE(f.src_col >= 0, CTR_EINVAL);
+    }
+    if (f.kind == CTR_FIELD_BAG) {
+      CTR_REQUIRE(f.bag_size > 0 && f.bag_size == f.vocab && f.src_col + f.bag_size <= ldx, CTR_EINVAL);
+      if (backward && f.grad) bag_floats += f.bag_size * f.width;
+    }
+    if (f.kind == CTR_FIELD_DENSE) {
+      CTR_REQUIRE(f.src_col + f.width <= ldx, CTR_EINVAL);
+      vec4 = vec4 && ctr_aligned16(x) && (ldx % 4 == 0) && (f.src_col % 4 == 0);
+    }
+    if (backward) {
+      if (f.grad) vec4 = vec4 && ctr_aligned16(f.grad);
+      if (f.kind == CTR_FIELD_PROD_I64 && f.grad2) vec4 = vec4 && ctr_aligned16(f.grad2);
+    }
+    vec4 = vec4 && (f.width % 4 == 0) && (f.out_col % 4 == 0);
+    floats += f.width;
+    plan->pack.f[i] = f;
+  }
+  if (needs_x) CTR_REQUIRE(x && ldx > 0, CTR_EINVAL);
+  plan->vec = vec4 ? 4 : 1;
+  plan->units = floats / plan->vec;
+  plan->bag_floats = bag_floats;
+  CTR_REQUIRE(plan->units <= kMaxUnits, CTR_ELIMIT);
+  CTR_REQUIRE(bag_floats * 4 <= 96 * 1024, CTR_ELIMIT);
+  return CTR_OK;
+}
+
+}  // namespace
+
+extern "C" int ctr_embed_fwd(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch,
+                             float* out, int64_t ldo, int32_t* err_flag, void* stream) {
+  CTR_REQUIRE(batch >= 0, CTR_EINVAL);
+  if (batch == 0) return CTR_OK;  // empty batch: nothing to read, pointers may be null
+  CTR_REQUIRE(ldo > 0, CTR_EINVAL);
+  Plan plan;
+  int rc = make_plan(fields, nfields, x, ldx, out, ldo, false, &plan);
+  if (rc != CTR_OK) return rc;
+  CTR_REQUIRE(batch < (1ll << 31), CTR_ELIMIT);
+  const int grid = ctr_stream_grid(batch * plan.units, kBlock);
+  hipStream_t st = (hipStream_t)stream;
+  if (plan.vec == 4)
+    hipLaunchKernelGGL(embed_fwd_kernel<4>, dim3(grid), dim3(kBlock), 0, st, plan.pack, nfields, x, ldx,
+                       (uint32_t)batch, out, ldo, err_flag);
+  else
+    hipLaunchKernelGGL(embed_fwd_kernel<1>, dim3(grid), dim3(kBlock), 0, st, plan.pack, nfields, x, ldx,
+                       (uint32_t)batch, out, ldo, err_flag);
+  return ctr_launch_status();
+}
+
+extern "C" int ctr_embed_bwd(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch,
+                             const float* gout, int64_t ldo, void* stream) {
+  CTR_REQUIRE(batch >= 0, CTR_EINVAL);
+  if (batch == 0) return CTR_OK;
+  CTR_REQUIRE(ldo > 0, CTR_EINVAL);
+  Plan plan;
+  int rc = make_plan(fields, nfields, x, ldx, gout, ldo, true, &plan);
+  if (rc != CTR_OK) return rc;
+  CTR_REQUIRE(batch < (1ll << 31), CTR_ELIMIT);
+  int grid = ctr_stream_grid(batch * plan.units, kBlock);
+  // every block flushes its LDS bag accumulators with global atomics: keep the
+  // flush small next to the payload
+  const int cap = plan.bag_floats > 4096 ? 256 : 1024;
+  if (grid > cap) grid = cap;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t dyn = (size_t)plan.bag_floats * sizeof(float);
+  if (plan.vec == 4)
+    hipLaunchKernelGGL(embed_bwd_kernel<4>, dim3(grid), dim3(kBlock), dyn, st, plan.pack, nfields, x, ldx,
+                       (uint32_t)batch, gout, ldo, plan.bag_floats);
+  else
+    hipLaunchKernelGGL(embed_bwd_kernel<1>, dim3(grid), dim3(kBlock), dyn, st, plan.pack, nfields, x, ldx,
+                       (uint32_t)batch, gout, ldo, plan.bag_floats);
+  return ctr_launch_status();
+}

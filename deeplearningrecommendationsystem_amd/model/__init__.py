@@ -1,0 +1,7 @@
+"""Drop-in counterparts of the reference's ``model/*.py`` classes: same class
+names, constructor arguments, parameter names (state_dict keys) and ``forward``
+signatures; forward/backward run on libctrhip's gfx950 kernels."""
+from .mf import MatrixFactorization
+from .neuralcf import NeuralCF
+
+__all__ = ["MatrixFactorization", "NeuralCF"]

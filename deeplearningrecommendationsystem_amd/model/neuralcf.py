@@ -1,0 +1,121 @@
+"""NeuralCF -- counterpart of the reference's model/neuralcf.py:7-72."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn.init import xavier_normal_
+
+from .. import ops
+from ..ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, FieldSpec, Layer
+from .._lib import FIELD_ID_I64, FIELD_PROD_I64
+from ._base import CtrModule
+
+
+class _NeuralCFFunction(torch.autograd.Function):
+    """inputs: user_idx, item_idx, err_flag, n_hidden, then parameters in the
+    order GMF_U, GMF_I, MLP_U, MLP_I, (W,b) x n_hidden, linear W,b, linear2 W,b.
+
+    Buffer layout (one (B, L0 + 2*mf) matrix, no torch.cat anywhere):
+        [ MLP_U[u] | MLP_I[i] |  GMF_U[u]*GMF_I[i] | linear(h) ]
+          `-- MLP input x0 --'   `------ input of linear2 -----'
+    """
+
+    @staticmethod
+    def forward(ctx, user_idx, item_idx, err_flag, n_hidden, gmf_u, gmf_i, mlp_u, mlp_i, *dense):
+        batch = user_idx.numel()
+        mf, half = gmf_u.shape[1], mlp_u.shape[1]
+        l0 = 2 * half
+        buf = torch.empty((batch, l0 + 2 * mf), dtype=torch.float32, device=gmf_u.device)
+        specs = _specs(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i)
+        ops.embed_fwd(specs, None, batch, buf, err_flag)
+        hidden = [Layer(dense[2 * k], dense[2 * k + 1], ACT_RELU) for k in range(n_hidden)]
+        proj = Layer(dense[2 * n_hidden], dense[2 * n_hidden + 1], ACT_NONE)
+        head = Layer(dense[2 * n_hidden + 2], dense[2 * n_hidden + 3], ACT_SIGMOID)
+        acts = ops.mlp_fwd(buf[:, :l0], hidden + [proj], last_out=buf[:, l0 + mf:])
+        prob = ops.linear_fwd(buf[:, l0:], head.weight, head.bias, ACT_SIGMOID)
+        ctx.n_hidden = n_hidden
+        ctx.save_for_backward(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i, buf, prob, *acts[1:-1], *dense)
+        return prob
+
+    @staticmethod
+    def backward(ctx, gprob):
+        n_hidden = ctx.n_hidden
+        saved = ctx.saved_tensors
+        user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i, buf, prob = saved[:8]
+        mids = list(saved[8:8 + n_hidden])
+        dense = saved[8 + n_hidden:]
+        batch = user_idx.numel()
+        mf, l0 = gmf_u.shape[1], 2 * mlp_u.shape[1]
+        hidden = [Layer(dense[2 * k], dense[2 * k + 1], ACT_RELU) for k in range(n_hidden)]
+        proj = Layer(dense[2 * n_hidden], dense[2 * n_hidden + 1], ACT_NONE)
+        head = Layer(dense[2 * n_hidden + 2], dense[2 * n_hidden + 3], ACT_SIGMOID)
+
+        gbuf = torch.empty_like(buf)
+        g_head_w, g_head_b = torch.zeros_like(head.weight), torch.zeros_like(head.bias)
+        ops.linear_bwd(buf[:, l0:], head.weight, prob, gprob.contiguous(), ACT_SIGMOID, gbuf[:, l0:],
+                       g_head_w, g_head_b)
+        acts = [buf[:, :l0]] + mids + [buf[:, l0 + mf:]]
+        layer_grads, _ = ops.mlp_bwd(acts, hidden + [proj], gbuf[:, l0 + mf:], gbuf[:, :l0])
+        tables = (gmf_u, gmf_i, mlp_u, mlp_i)
+        tgrads = {id(t): torch.zeros_like(t) for t in tables}
+        ops.embed_bwd(_specs(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i), None, batch, gbuf, tgrads)
+        out = [None, None, None, None] + [tgrads[id(t)] for t in tables]
+        for gw, gb in layer_grads:
+            out += [gw, gb]
+        out += [g_head_w, g_head_b]
+        return tuple(out)
+
+
+def _specs(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i):
+    mf, half = gmf_u.shape[1], mlp_u.shape[1]
+    l0 = 2 * half
+    return [
+        FieldSpec(FIELD_ID_I64, half, 0, table=mlp_u, idx=user_idx),
+        FieldSpec(FIELD_ID_I64, half, half, table=mlp_i, idx=item_idx),
+        FieldSpec(FIELD_PROD_I64, mf, l0, table=gmf_u, idx=user_idx, table2=gmf_i, idx2=item_idx),
+    ]
+
+
+class NeuralCF(CtrModule):
+    """``NeuralCF(num_user, num_item, mf_dim, layers)``;
+    ``forward(user_indices, item_indices) -> (B,1)`` (reference
+    model/neuralcf.py:8-59)."""
+
+    def __init__(self, num_user, num_item, mf_dim, layers):
+        super().__init__()
+        self.GMF_Embedding_User = nn.Embedding(num_user, mf_dim)
+        self.GMF_Embedding_Item = nn.Embedding(num_item, mf_dim)
+        self.MLP_Embedding_User = nn.Embedding(num_user, int(layers[0] / 2))
+        self.MLP_Embedding_Item = nn.Embedding(num_item, int(layers[0] / 2))
+        for emb in (self.GMF_Embedding_User, self.GMF_Embedding_Item, self.MLP_Embedding_User,
+                    self.MLP_Embedding_Item):
+            xavier_normal_(emb.weight.data)
+        self.dnn_network = nn.ModuleList([nn.Linear(a, b) for a, b in zip(layers[:-1], layers[1:])])
+        self.relu = nn.ReLU()
+        self.linear = nn.Linear(layers[-1], mf_dim)
+        self.linear2 = nn.Linear(2 * mf_dim, 1)
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, user_indices, item_indices):
+        w = self.GMF_Embedding_User.weight
+        self._need_device(w, user_indices, item_indices)
+        dense = []
+        for lin in list(self.dnn_network) + [self.linear, self.linear2]:
+            dense += [lin.weight, lin.bias]
+        out = _NeuralCFFunction.apply(user_indices.contiguous(), item_indices.contiguous(), self._err_flag(w.device),
+                                      len(self.dnn_network), w, self.GMF_Embedding_Item.weight,
+                                      self.MLP_Embedding_User.weight, self.MLP_Embedding_Item.weight, *dense)
+        self._raise_if_bad_index()
+        return out
+
+    def recommendation(self, num_users, num_items):
+        """score every (user, item) pair and rank (reference model/neuralcf.py:61-72)"""
+        rows = []
+        dev = self.GMF_Embedding_User.weight.device
+        items = torch.arange(num_items, device=dev)
+        with torch.no_grad():
+            for u in range(num_users):
+                scores = self.forward(torch.full((num_items,), u, device=dev), items)
+                rows.append(torch.topk(scores, num_items, dim=0).indices.view(-1).tolist())
+        return np.array(rows)

@@ -1,0 +1,297 @@
+"""Host-side wrappers over the C ABI (include/ctrhip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every function
+passes raw pointers + leading dimensions to libctrhip and enqueues on torch's
+current stream.  2-D operands may be column slices of a wider buffer (stride(1)
+must be 1), which is how the reference's ``torch.cat`` calls disappear: producers
+write straight into the consumer's operand.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, FIELD_BAG, FIELD_DENSE, FIELD_ID_F32, FIELD_ID_I64,
+                   FIELD_PROD_I64, Field)
+
+__all__ = ["FieldSpec", "embed_fwd", "embed_bwd", "linear_fwd", "linear_bwd", "mf_fwd", "mf_bwd",
+           "ACT_NONE", "ACT_RELU", "ACT_SIGMOID"]
+
+
+# ---------------------------------------------------------------------------
+# optional per-launch timing (bench.py): a HIP event pair on the stream the
+# kernel is enqueued on, plus the launch's algorithmic bytes / flops
+# ---------------------------------------------------------------------------
+class KernelProfiler:
+    def __init__(self):
+        self.records = []
+
+    def add(self, label, nbytes, flops, start, end):
+        self.records.append((label, nbytes, flops, start, end))
+
+    def summary(self):
+        """{label: dict(calls, avg_us, bytes, flops)} -- call after a sync"""
+        torch.cuda.synchronize()
+        out = {}
+        for label, nbytes, flops, start, end in self.records:
+            d = out.setdefault(label, dict(calls=0, total_us=0.0, bytes=nbytes, flops=flops))
+            d["calls"] += 1
+            d["total_us"] += start.elapsed_time(end) * 1e3
+        for d in out.values():
+            d["avg_us"] = d["total_us"] / d["calls"]
+        return out
+
+
+_profiler: Optional[KernelProfiler] = None
+
+
+def set_profiler(p: Optional[KernelProfiler]) -> None:
+    global _profiler
+    _profiler = p
+
+
+def _timed(label, meta, fn, *args):
+    """run one C call; when a profiler is installed bracket it with events"""
+    p = _profiler
+    if p is None:
+        return fn(*args)
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    rc = fn(*args)
+    end.record()
+    nbytes, flops = meta()
+    p.add(label, nbytes, flops, start, end)
+    return rc
+
+
+def _embed_bytes(specs, batch, backward):
+    """algorithmic HBM bytes of one embedding-stage launch"""
+    rows = idx = xcols = out = small = 0
+    seen = set()
+    for s in specs:
+        out += s.width * 4
+        for t in (s.idx, s.idx2):
+            if t is not None and t.data_ptr() not in seen:
+                seen.add(t.data_ptr())
+                idx += 8
+        if s.kind in (FIELD_ID_I64, FIELD_ID_F32):
+            rows += s.width * 4
+            xcols += 4 if s.kind == FIELD_ID_F32 else 0
+        elif s.kind == FIELD_PROD_I64:
+            rows += 2 * s.width * 4
+        elif s.kind == FIELD_BAG:
+            xcols += 4 * s.bag_size
+            small += s.bag_size * s.width * 4
+        else:
+            xcols += 4 * s.width
+    if not backward:
+        return batch * (rows + idx + xcols + out) + small
+    # backward: read gout, idx, (PROD: both rows), read-modify-write each touched grad row
+    prod_rows = sum(2 * s.width * 4 for s in specs if s.kind == FIELD_PROD_I64)
+    return batch * (out + idx + xcols + prod_rows + 2 * rows) + 2 * small
+
+
+def _mat(t: torch.Tensor, what: str) -> torch.Tensor:
+    if t.dim() != 2 or t.dtype != torch.float32 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError(f"{what}: expected a 2-D float32 tensor with unit inner stride, got "
+                         f"{tuple(t.shape)} {t.dtype} strides {t.stride()}")
+    _lib.require_device(t)
+    return t
+
+
+def _ld(t: torch.Tensor) -> int:
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+
+
+@dataclass
+class FieldSpec:
+    """one output slice of the embedding stage (mirror of ``ctr_field_t``)"""
+    kind: int
+    width: int
+    out_col: int
+    table: Optional[torch.Tensor] = None      # (vocab, width) parameter
+    src_col: int = 0
+    bag_size: int = 0
+    idx: Optional[torch.Tensor] = None        # int64, (B,) or a column of (B,L)
+    idx_stride: int = 1
+    table2: Optional[torch.Tensor] = None
+    idx2: Optional[torch.Tensor] = None
+
+
+def _field_array(specs: Sequence[FieldSpec], grads=None):
+    if len(specs) > _lib.CTR_MAX_FIELDS:
+        raise ValueError(f"at most {_lib.CTR_MAX_FIELDS} fields per launch")
+    arr = (Field * len(specs))()
+    for k, s in enumerate(specs):
+        f = arr[k]
+        f.kind, f.width, f.out_col, f.src_col, f.bag_size = s.kind, s.width, s.out_col, s.src_col, s.bag_size
+        f.idx_stride = s.idx_stride
+        if s.table is not None:
+            _lib.require_device(s.table)
+            if s.table.dtype != torch.float32 or not s.table.is_contiguous() or s.table.shape[1] != s.width:
+                raise ValueError("embedding table must be contiguous float32 (vocab, width)")
+            f.vocab = s.table.shape[0]
+            f.table = s.table.data_ptr()
+        if s.idx is not None:
+            _lib.require_device(s.idx)
+            if s.idx.dtype != torch.int64:
+                raise ValueError("indices must be int64")
+            f.idx = s.idx.data_ptr()
+        if s.table2 is not None:
+            f.vocab2 = s.table2.shape[0]
+            f.table2 = s.table2.data_ptr()
+            f.idx2 = s.idx2.data_ptr()
+        if grads is not None:
+            g = grads.get(id(s.table)) if s.table is not None else None
+            f.grad = None if g is None else g.data_ptr()
+            g2 = grads.get(id(s.table2)) if s.table2 is not None else None
+            f.grad2 = None if g2 is None else g2.data_ptr()
+    return arr
+
+
+def embed_fwd(specs: Sequence[FieldSpec], x: Optional[torch.Tensor], batch: int, out: torch.Tensor,
+              err_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fused gather + bag pooling + concat into ``out`` (B, >= sum widths)"""
+    out = _mat(out, "out")
+    if x is not None:
+        x = _mat(x, "x")
+    arr = _field_array(specs)
+    rc = _timed("embed_fwd", lambda: (_embed_bytes(specs, batch, False), 0),
+                _lib.load().ctr_embed_fwd, arr, len(specs), _lib.ptr(x), _ld(x) if x is not None else 0, batch,
+                out.data_ptr(), _ld(out), _lib.ptr(err_flag), _lib.stream_ptr())
+    _lib.check(rc, "ctr_embed_fwd")
+    return out
+
+
+def embed_bwd(specs: Sequence[FieldSpec], x: Optional[torch.Tensor], batch: int, gout: torch.Tensor,
+              grads: dict) -> None:
+    """accumulate into ``grads[id(table)]`` (dense, same shape as the table)"""
+    gout = _mat(gout, "gout")
+    if x is not None:
+        x = _mat(x, "x")
+    arr = _field_array(specs, grads)
+    rc = _timed("embed_bwd", lambda: (_embed_bytes(specs, batch, True), 0),
+                _lib.load().ctr_embed_bwd, arr, len(specs), _lib.ptr(x), _ld(x) if x is not None else 0, batch,
+                gout.data_ptr(), _ld(gout), _lib.stream_ptr())
+    _lib.check(rc, "ctr_embed_bwd")
+
+
+def linear_fwd(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int = ACT_NONE,
+               out: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act(x @ w.T + b (+ residual)); ``w`` is nn.Linear's (out, in) weight"""
+    x, w = _mat(x, "x"), _mat(w, "w")
+    m, k = x.shape
+    n = w.shape[0]
+    if w.shape[1] != k:
+        raise ValueError(f"linear: x has {k} columns, weight expects {w.shape[1]}")
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    out = _mat(out, "out")
+    if residual is not None:
+        residual = _mat(residual, "residual")
+    rc = _timed(f"linear_fwd[{m}x{n}x{k}]",
+                lambda: (4 * (m * k + n * k + n + m * n * (2 if residual is not None else 1)), 2 * m * n * k),
+                _lib.load().ctr_linear_fwd, x.data_ptr(), _ld(x), w.data_ptr(), _ld(w), _lib.ptr(b),
+                _lib.ptr(residual), _ld(residual) if residual is not None else 0, out.data_ptr(), _ld(out),
+                m, n, k, act, _lib.stream_ptr())
+    _lib.check(rc, "ctr_linear_fwd")
+    return out
+
+
+def linear_bwd(x: torch.Tensor, w: torch.Tensor, y: Optional[torch.Tensor], gy: torch.Tensor, act: int,
+               gx: Optional[torch.Tensor], gw: Optional[torch.Tensor], gb: Optional[torch.Tensor],
+               accumulate_gx: bool = False) -> None:
+    """gz = gy*act'(y); gx (=|+=) gz @ w; gw += gz.T @ x; gb += gz.sum(0)"""
+    x, w, gy = _mat(x, "x"), _mat(w, "w"), _mat(gy, "gy")
+    m, k = x.shape
+    n = w.shape[0]
+    if y is not None:
+        y = _mat(y, "y")
+    if gx is not None:
+        gx = _mat(gx, "gx")
+    fn = _lib.load().ctr_linear_bwd
+    ygy = 4 * m * n * (2 if (y is not None and act != ACT_NONE) else 1)
+
+    def call(gx_, gw_, gb_):
+        return (x.data_ptr(), _ld(x), w.data_ptr(), _ld(w), _lib.ptr(y), _ld(y) if y is not None else 0,
+                gy.data_ptr(), _ld(gy), _lib.ptr(gx_), _ld(gx_) if gx_ is not None else 0, int(accumulate_gx),
+                _lib.ptr(gw_), _ld(gw_) if gw_ is not None else 0, _lib.ptr(gb_), m, n, k, act, _lib.stream_ptr())
+
+    if _profiler is None:
+        _lib.check(fn(*call(gx, gw, gb)), "ctr_linear_bwd")
+        return
+    # profiling: one C call per kernel so each gets its own event pair
+    if gx is not None:
+        _lib.check(_timed(f"linear_bwd_dx[{m}x{n}x{k}]", lambda: (ygy + 4 * (n * k + m * k), 2 * m * n * k),
+                          fn, *call(gx, None, None)), "ctr_linear_bwd")
+    if gw is not None:
+        _lib.check(_timed(f"linear_bwd_dw[{m}x{n}x{k}]", lambda: (ygy + 4 * (m * k + 2 * n * k), 2 * m * n * k),
+                          fn, *call(None, gw, gb)), "ctr_linear_bwd")
+
+
+def mf_fwd(user_table, item_table, user_idx, item_idx, err_flag=None) -> torch.Tensor:
+    _lib.require_device(user_table, item_table, user_idx, item_idx)
+    batch = user_idx.numel()
+    prob = torch.empty(batch, dtype=torch.float32, device=user_table.device)
+    dim = user_table.shape[1]
+    rc = _timed("mf_fwd", lambda: (batch * (8 * dim + 16 + 4), 2 * batch * dim),
+                _lib.load().ctr_mf_fwd, user_table.data_ptr(), user_table.shape[0], item_table.data_ptr(),
+                item_table.shape[0], dim, user_idx.data_ptr(), item_idx.data_ptr(), batch, prob.data_ptr(),
+                _lib.ptr(err_flag), _lib.stream_ptr())
+    _lib.check(rc, "ctr_mf_fwd")
+    return prob
+
+
+def mf_bwd(user_table, item_table, user_idx, item_idx, prob, gprob, guser, gitem) -> None:
+    dim, batch = user_table.shape[1], user_idx.numel()
+    rc = _timed("mf_bwd", lambda: (batch * (8 * dim + 16 + 8 + 16 * dim), 4 * batch * dim),
+                _lib.load().ctr_mf_bwd, user_table.data_ptr(), user_table.shape[0], item_table.data_ptr(),
+                item_table.shape[0], dim, user_idx.data_ptr(), item_idx.data_ptr(), batch, prob.data_ptr(),
+                gprob.data_ptr(), _lib.ptr(guser), _lib.ptr(gitem), _lib.stream_ptr())
+    _lib.check(rc, "ctr_mf_bwd")
+
+
+# ---------------------------------------------------------------------------
+# a stack of nn.Linear(+activation) layers, forward and hand-written backward
+# ---------------------------------------------------------------------------
+@dataclass
+class Layer:
+    weight: torch.Tensor
+    bias: Optional[torch.Tensor]
+    act: int
+
+
+def mlp_fwd(x: torch.Tensor, layers: Sequence[Layer], last_out: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+    """returns [x, y_1, ..., y_n]; the last layer may write into ``last_out``"""
+    acts = [x]
+    for k, layer in enumerate(layers):
+        out = last_out if (k == len(layers) - 1) else None
+        acts.append(linear_fwd(acts[-1], layer.weight, layer.bias, layer.act, out=out))
+    return acts
+
+
+def mlp_bwd(acts: Sequence[torch.Tensor], layers: Sequence[Layer], gy: torch.Tensor,
+            gx_first: Optional[torch.Tensor], want_gx_first: bool = True):
+    """backward through ``mlp_fwd``; returns ([(gw, gb) per layer], gx of the
+    first layer input or None)"""
+    grads = [None] * len(layers)
+    g = gy
+    for k in range(len(layers) - 1, -1, -1):
+        layer = layers[k]
+        xin, yout = acts[k], acts[k + 1]
+        gw = torch.zeros_like(layer.weight)
+        gb = torch.zeros_like(layer.bias) if layer.bias is not None else None
+        if k > 0:
+            gx = torch.empty((xin.shape[0], xin.shape[1]), dtype=torch.float32, device=xin.device)
+        else:
+            gx = gx_first if want_gx_first else None
+            if want_gx_first and gx is None:
+                gx = torch.empty((xin.shape[0], xin.shape[1]), dtype=torch.float32, device=xin.device)
+        linear_bwd(xin, layer.weight, yout, g, layer.act, gx, gw, gb)
+        grads[k] = (gw, gb)
+        g = gx
+    return grads, g

@@ -1,0 +1,130 @@
+/*
+ * ctrhip.h -- C ABI of libctrhip.so: hand-written gfx950 (MI355X) kernels for the
+ * forward/backward of a CTR model zoo.
+ *
+ * The reference (WardellZc/DeepLearningRecommendationSystem) has no FFI layer:
+ * its hot path is `model/<m>.py: nn.Module.forward` + autograd, called from
+ * `trainer/trainer.py:23-40`.  These entry points are what a binding for that
+ * path binds instead of ATen ops; each declaration names the reference lines
+ * it replaces.  INTEGRATION.md shows the ctypes stub a maintainer adds.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the comment says "host";
+ *  - tensors are fp32, row-major, with an explicit leading dimension in
+ *    elements (ld*); indices are int64 as `nn.Embedding` takes them;
+ *  - `stream` is a hipStream_t; every call only enqueues work on it, never
+ *    allocates, never synchronises, keeps no state between calls and is
+ *    re-entrant per stream;
+ *  - return value: 0 = enqueued, <0 = CTR_E* (nothing enqueued).  Never
+ *    throws, never exits.  ctr_strerror() names a code;
+ *  - out-of-range indices never fault: the row is treated as row 0 and, when
+ *    `err_flag` (device int32, may be NULL) is given, it is set to 1 so the
+ *    host can raise the IndexError `nn.Embedding` would have raised.
+ */
+#ifndef CTRHIP_H
+#define CTRHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTR_OK 0
+#define CTR_EINVAL (-1)   /* bad argument (null pointer, negative size, bad kind) */
+#define CTR_ELIMIT (-2)   /* shape outside what the kernels are built for */
+#define CTR_ELAUNCH (-3)  /* hipLaunchKernel reported an error */
+#define CTR_EALIGN (-4)   /* pointer / leading dimension not aligned as required */
+
+int ctr_version(void);                 /* ABI version, bumped on any signature change */
+const char* ctr_strerror(int code);    /* host string, static storage */
+const char* ctr_target_arch(void);     /* "gfx950" */
+
+/* ------------------------------------------------------------------------
+ * Embedding stage: fused row gather + weighted bag pooling + concat.
+ * Replaces the nn.Embedding calls, the "multi-hot matmul" poolings and the
+ * torch.cat that follows them:
+ *   model/pnn.py:113-121, model/deepfm.py:45-54, model/deepcrossing.py:63-71,
+ *   model/ffm.py:48-59, model/neuralcf.py:36-46, model/mf.py:24-25.
+ * One launch writes, for every sample b and field f, `width` floats at
+ * out[b*ldo + out_col ...].
+ * ---------------------------------------------------------------------- */
+enum {
+  CTR_FIELD_ID_I64 = 0,  /* out = table[idx[b*idx_stride]]                        (K1/K3) */
+  CTR_FIELD_ID_F32 = 1,  /* out = table[(int64)x[b*ldx+src_col]]  ("x[:,c].long()") (K1) */
+  CTR_FIELD_BAG = 2,     /* out = sum_j x[b*ldx+src_col+j] * table[j], j<bag_size  (K2) */
+  CTR_FIELD_DENSE = 3,   /* out = x[b*ldx+src_col .. +width)   (deepcrossing.py:65)      */
+  CTR_FIELD_PROD_I64 = 4 /* out = table[idx[b]] * table2[idx2[b]] (neuralcf.py:36-39)    */
+};
+#define CTR_MAX_FIELDS 32
+
+typedef struct ctr_field {
+  int32_t kind;
+  int32_t width;          /* floats written per sample (embedding dim E) */
+  int32_t out_col;        /* first output column */
+  int32_t src_col;        /* ID_F32 / BAG / DENSE: first column of x */
+  int32_t bag_size;       /* BAG: K (table has K rows) */
+  int32_t reserved;
+  int64_t vocab;          /* rows of `table` (bounds check) */
+  int64_t idx_stride;     /* ID_I64 / PROD: elements between consecutive samples */
+  const int64_t* idx;     /* ID_I64 / PROD */
+  const float* table;     /* (vocab, width) */
+  float* grad;            /* backward: dense (vocab, width) accumulator, NULL = skip */
+  const int64_t* idx2;    /* PROD only */
+  const float* table2;    /* PROD only, (vocab2, width) */
+  float* grad2;           /* PROD only */
+  int64_t vocab2;         /* PROD only */
+} ctr_field_t;
+
+/* fields: host array of nfields (<= CTR_MAX_FIELDS) descriptors, copied by value */
+int ctr_embed_fwd(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx,
+                  int64_t batch, float* out, int64_t ldo, int32_t* err_flag, void* stream);
+
+/* backward of ctr_embed_fwd (autograd of the lines above; embedding_dense_backward
+ * and the `x^T g` matmul backward, trainer/trainer.py:38): accumulates
+ * (+=) into each field's dense `grad`; the caller zero-fills it first when it
+ * wants a fresh gradient.  fp32 atomics: order of accumulation is not fixed. */
+int ctr_embed_bwd(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx,
+                  int64_t batch, const float* gout, int64_t ldo, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Matrix factorisation, fused (model/mf.py:23-26):
+ *   prob[b] = sigmoid(sum_e U[u[b],e] * V[i[b],e])
+ * bwd: dlogit = gprob*prob*(1-prob); dU[u[b]] += dlogit*V[i[b]]; dV likewise.
+ * ---------------------------------------------------------------------- */
+int ctr_mf_fwd(const float* user_table, int64_t num_users, const float* item_table, int64_t num_items,
+               int dim, const int64_t* user_idx, const int64_t* item_idx, int64_t batch,
+               float* prob, int32_t* err_flag, void* stream);
+int ctr_mf_bwd(const float* user_table, int64_t num_users, const float* item_table, int64_t num_items,
+               int dim, const int64_t* user_idx, const int64_t* item_idx, int64_t batch,
+               const float* prob, const float* gprob, float* guser, float* gitem, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Dense layers (every nn.Linear of the zoo, e.g. model/neuralcf.py:48-51,57,
+ * model/pnn.py:18-23,75-76, model/deepfm.py:57-60, model/din.py:14-29).
+ *   Y[m, n] = act( sum_k X[m,k] * W[n,k] + bias[n] (+ R[m,n]) )
+ * W is nn.Linear's (out_features, in_features) layout.  fp32 in, fp32 MFMA
+ * accumulate (v_mfma_f32_32x32x2_f32), fp32 out.
+ * ---------------------------------------------------------------------- */
+enum { CTR_ACT_NONE = 0, CTR_ACT_RELU = 1, CTR_ACT_SIGMOID = 2 };
+
+int ctr_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias /*nullable*/,
+                   const float* residual /*nullable*/, int64_t ldr,
+                   float* y, int64_t ldy, int64_t m, int n, int k, int act, void* stream);
+
+/* gz = gy * act'(y) (uses the saved OUTPUT y: relu mask y>0, sigmoid y(1-y));
+ * gx[m,k] = sum_n gz[m,n] W[n,k]      (skipped when gx == NULL;  += when accumulate_gx)
+ * gw[n,k] += sum_m gz[m,n] X[m,k]     (skipped when gw == NULL)
+ * gb[n]  += sum_m gz[m,n]             (skipped when gb == NULL; needs gw)
+ * Autograd of the nn.Linear + activation lines above (trainer/trainer.py:38).
+ * gw/gb accumulate with fp32 atomics over row chunks: the caller zero-fills. */
+int ctr_linear_bwd(const float* x, int64_t ldx, const float* w, int64_t ldw,
+                   const float* y, int64_t ldy, const float* gy, int64_t ldgy,
+                   float* gx, int64_t ldgx, int accumulate_gx,
+                   float* gw, int64_t ldgw, float* gb,
+                   int64_t m, int n, int k, int act, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTRHIP_H */

@@ -1,0 +1,211 @@
+"""GPU: op-level parity of libctrhip kernels (called through the C ABI) against
+the CPU oracle / an fp64 torch reference.
+
+Tolerances: index work (row gather, one-hot bags, dense copies) is bit-exact;
+fp32 sums are compared at rtol 1e-5 (north_star: "within 1e-5 relative")."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ctr_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from deeplearningrecommendationsystem_amd import ops as o
+    return o
+
+
+def _lib():
+    from deeplearningrecommendationsystem_amd import _lib
+    return _lib
+
+
+def _feature_specs(ops, tabs, widths_e, ldo_cols=True):
+    L = _lib()
+    e = widths_e
+    return [
+        ops.FieldSpec(L.FIELD_ID_F32, e, 0 * e, table=tabs["user"], src_col=0),
+        ops.FieldSpec(L.FIELD_ID_F32, e, 1 * e, table=tabs["item"], src_col=1),
+        ops.FieldSpec(L.FIELD_BAG, e, 2 * e, table=tabs["age"], src_col=2, bag_size=1),
+        ops.FieldSpec(L.FIELD_BAG, e, 3 * e, table=tabs["gender"], src_col=3, bag_size=2),
+        ops.FieldSpec(L.FIELD_BAG, e, 4 * e, table=tabs["occ"], src_col=5, bag_size=21),
+        ops.FieldSpec(L.FIELD_BAG, e, 5 * e, table=tabs["genre"], src_col=26, bag_size=19),
+    ]
+
+
+@pytest.mark.parametrize("e,batch", [(16, 1000), (8, 37), (4, 1), (64, 4096), (6, 129), (1, 77)])
+def test_embed_stage_forward_and_backward(ops, e, batch):
+    from deeplearningrecommendationsystem_amd import synth
+    g = synth.generator(e * 1000 + batch)
+    x = synth.feature_batch(batch, 50, 70, g, zero_genre_rows=min(3, batch))
+    tabs = {k: torch.randn(v, e, generator=g) for k, v in
+            dict(user=50, item=70, age=1, gender=2, occ=21, genre=19).items()}
+    dt = {k: v.to(DEV) for k, v in tabs.items()}
+    specs = _feature_specs(ops, dt, e)
+    out = torch.full((batch, 6 * e), float("nan"), device=DEV)
+    ops.embed_fwd(specs, x.to(DEV), batch, out)
+    out = out.cpu()
+    uid, iid = x[:, 0].long(), x[:, 1].long()
+    # id rows and one-hot bags: bit-exact
+    assert torch.equal(out[:, 0:e], orc.gather_rows(tabs["user"], uid))
+    assert torch.equal(out[:, e:2 * e], orc.gather_rows(tabs["item"], iid))
+    assert torch.equal(out[:, 3 * e:4 * e], orc.gather_rows(tabs["gender"], x[:, 3:5].argmax(1)))
+    assert torch.equal(out[:, 4 * e:5 * e], orc.gather_rows(tabs["occ"], x[:, 5:26].argmax(1)))
+    # real-weighted / multi-hot bags: fp32 sums
+    torch.testing.assert_close(out[:, 2 * e:3 * e], orc.bag_pool(x[:, 2:3], tabs["age"]), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(out[:, 5 * e:6 * e], orc.bag_pool(x[:, 26:45], tabs["genre"]), rtol=1e-6, atol=1e-6)
+
+    # backward: dense grads of every table vs autograd of the oracle restatement
+    gout = torch.randn(batch, 6 * e, generator=g)
+    # (fp64 reference: the bag tables' gradients are sums over the whole batch)
+    leaf = {k: v.double().requires_grad_(True) for k, v in tabs.items()}
+    xd = x.double()
+    ref = torch.cat([leaf["user"][uid], leaf["item"][iid], xd[:, 2:3] @ leaf["age"], xd[:, 3:5] @ leaf["gender"],
+                     xd[:, 5:26] @ leaf["occ"], xd[:, 26:45] @ leaf["genre"]], dim=1)
+    ref.backward(gout.double())
+    grads = {id(dt[k]): torch.zeros_like(dt[k]) for k in dt}
+    ops.embed_bwd(specs, x.to(DEV), batch, gout.to(DEV), grads)
+    for k in tabs:
+        torch.testing.assert_close(grads[id(dt[k])].cpu(), leaf[k].grad.float(), rtol=1e-5,
+                                   atol=1e-6 + 3e-6 * batch ** 0.5, msg=lambda m, k=k: f"grad of {k}: {m}")
+
+
+def test_embed_id_i64_prod_dense_and_strided_output(ops):
+    L = _lib()
+    g = torch.Generator().manual_seed(5)
+    batch, e = 333, 12
+    t1, t2 = torch.randn(40, e, generator=g), torch.randn(30, e, generator=g)
+    i1 = torch.randint(0, 40, (batch,), generator=g)
+    i2 = torch.randint(0, 30, (batch,), generator=g)
+    x = torch.randn(batch, 7, generator=g)
+    d1, d2, di1, di2 = t1.to(DEV), t2.to(DEV), i1.to(DEV), i2.to(DEV)
+    specs = [
+        ops.FieldSpec(L.FIELD_ID_I64, e, 0, table=d1, idx=di1),
+        ops.FieldSpec(L.FIELD_DENSE, 3, e, src_col=2),
+        ops.FieldSpec(L.FIELD_PROD_I64, e, e + 3, table=d1, idx=di1, table2=d2, idx2=di2),
+    ]
+    wide = torch.zeros(batch, 2 * e + 3 + 5, device=DEV)  # wider than the fields: ld > used columns
+    ops.embed_fwd(specs, x.to(DEV), batch, wide)
+    w = wide.cpu()
+    assert torch.equal(w[:, :e], t1[i1])
+    assert torch.equal(w[:, e:e + 3], x[:, 2:5])
+    assert torch.equal(w[:, e + 3:2 * e + 3], t1[i1] * t2[i2])
+    assert torch.equal(w[:, 2 * e + 3:], torch.zeros(batch, 5))
+
+    gout = torch.randn(batch, 2 * e + 8, generator=g)
+    l1, l2 = t1.clone().requires_grad_(True), t2.clone().requires_grad_(True)
+    (torch.cat([l1[i1], x[:, 2:5], l1[i1] * l2[i2]], 1) * gout[:, :2 * e + 3]).sum().backward()
+    grads = {id(d1): torch.zeros_like(d1), id(d2): torch.zeros_like(d2)}
+    ops.embed_bwd(specs, x.to(DEV), batch, gout.to(DEV), grads)
+    torch.testing.assert_close(grads[id(d1)].cpu(), l1.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(grads[id(d2)].cpu(), l2.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_embed_sequence_gather_is_bit_exact(ops):
+    # K3: (B,L) history gathered column by column through idx_stride
+    L = _lib()
+    g = torch.Generator().manual_seed(6)
+    batch, length, e = 50, 7, 8
+    table = torch.randn(100, e, generator=g)
+    hist = torch.randint(0, 100, (batch, length), generator=g)
+    dt, dh = table.to(DEV), hist.to(DEV)
+    specs = [ops.FieldSpec(L.FIELD_ID_I64, e, l * e, table=dt, idx=dh[:, l], idx_stride=length)
+             for l in range(length)]
+    out = torch.empty(batch, length * e, device=DEV)
+    ops.embed_fwd(specs, None, batch, out)
+    assert torch.equal(out.cpu().view(batch, length, e), orc.gather_rows(table, hist))
+
+
+def test_embed_out_of_range_index_sets_flag_and_does_not_fault(ops):
+    L = _lib()
+    table = torch.randn(10, 4).to(DEV)
+    idx = torch.tensor([1, 10, -1, 3]).to(DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    out = torch.empty(4, 4, device=DEV)
+    ops.embed_fwd([ops.FieldSpec(L.FIELD_ID_I64, 4, 0, table=table, idx=idx)], None, 4, out, flag)
+    assert flag.item() == 1
+    assert torch.equal(out[1], table[0]) and torch.equal(out[0], table[1])
+
+
+def test_embed_empty_batch(ops):
+    L = _lib()
+    table = torch.randn(10, 4).to(DEV)
+    idx = torch.zeros(0, dtype=torch.int64, device=DEV)
+    out = torch.empty(0, 4, device=DEV)
+    ops.embed_fwd([ops.FieldSpec(L.FIELD_ID_I64, 4, 0, table=table, idx=idx)], None, 0, out)
+
+
+LINEAR_SHAPES = [
+    # (m, n, k)
+    (1, 1, 1), (37, 5, 3), (64, 32, 32), (129, 33, 31), (1000, 64, 128), (513, 1, 128),
+    (300, 128, 96), (2048, 161, 256), (700, 256, 161), (257, 512, 48), (4096, 8, 16),
+]
+
+
+@pytest.mark.parametrize("m,n,k", LINEAR_SHAPES)
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear_forward(ops, m, n, k, act):
+    g = torch.Generator().manual_seed(m * 7 + n * 3 + k + act)
+    x, w, b = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5, torch.randn(n, generator=g)
+    y = ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), act).cpu()
+    ref = x.double() @ w.double().T + b.double()
+    ref = [ref, torch.relu(ref), torch.sigmoid(ref)][act]
+    torch.testing.assert_close(y, ref.float(), rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("m,n,k", LINEAR_SHAPES)
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear_backward(ops, m, n, k, act):
+    g = torch.Generator().manual_seed(m * 11 + n * 5 + k + act)
+    x = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g)
+    gy = torch.randn(m, n, generator=g)
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+    z = xd @ wd.T + bd
+    yd = [z, torch.relu(z), torch.sigmoid(z)][act]
+    yd.backward(gy.double())
+    dx, dw, dy, dgy = x.to(DEV), w.to(DEV), yd.detach().float().to(DEV), gy.to(DEV)
+    gx = torch.full((m, k), float("nan"), device=DEV)
+    gw, gb = torch.zeros(n, k, device=DEV), torch.zeros(n, device=DEV)
+    ops.linear_bwd(dx, dw, dy, dgy, act, gx, gw, gb)
+    scale = max(1.0, m ** 0.5)
+    torch.testing.assert_close(gx.cpu(), xd.grad.float(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gw.cpu(), wd.grad.float(), rtol=1e-5, atol=2e-6 * scale)
+    torch.testing.assert_close(gb.cpu(), bd.grad.float(), rtol=1e-5, atol=2e-6 * scale)
+
+
+def test_linear_strided_views_residual_and_accumulate(ops):
+    g = torch.Generator().manual_seed(9)
+    m, n, k = 200, 24, 40
+    big = torch.randn(m, 100, generator=g)
+    x = big[:, 10:10 + k]                       # column slice: ld = 100
+    w, b = torch.randn(n, k, generator=g), torch.randn(n, generator=g)
+    res = torch.randn(m, n, generator=g)
+    dbig = big.to(DEV)
+    outbuf = torch.zeros(m, 64, device=DEV)
+    ops.linear_fwd(dbig[:, 10:10 + k], w.to(DEV), b.to(DEV), 1, out=outbuf[:, 8:8 + n], residual=res.to(DEV))
+    ref = torch.relu(x.double() @ w.double().T + b.double() + res.double()).float()
+    torch.testing.assert_close(outbuf[:, 8:8 + n].cpu(), ref, rtol=1e-5, atol=2e-6)
+    assert torch.equal(outbuf[:, :8].cpu(), torch.zeros(m, 8))
+    assert torch.equal(outbuf[:, 8 + n:].cpu(), torch.zeros(m, 64 - 8 - n))
+    # accumulate_gx adds to what is there
+    gy = torch.randn(m, n, generator=g)
+    gx = torch.ones(m, k, device=DEV)
+    ops.linear_bwd(dbig[:, 10:10 + k], w.to(DEV), None, gy.to(DEV), 0, gx, None, None, accumulate_gx=True)
+    torch.testing.assert_close(gx.cpu(), (1.0 + gy.double() @ w.double()).float(), rtol=1e-5, atol=1e-5)
+
+
+def test_mf_fused_kernels(ops):
+    g = torch.Generator().manual_seed(3)
+    for dim, batch in [(64, 1024), (12, 37), (5, 3)]:
+        ut, it = torch.randn(30, dim, generator=g), torch.randn(40, dim, generator=g)
+        u, i = torch.randint(0, 30, (batch,), generator=g), torch.randint(0, 40, (batch,), generator=g)
+        prob = ops.mf_fwd(ut.to(DEV), it.to(DEV), u.to(DEV), i.to(DEV))
+        ref = orc.mf_forward({"user_embeddings.weight": ut, "item_embeddings.weight": it}, u, i)
+        torch.testing.assert_close(prob.cpu(), ref, rtol=1e-5, atol=1e-6)
