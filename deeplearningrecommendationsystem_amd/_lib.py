@@ -47,6 +47,16 @@ SIGNATURES = {
     "ctr_mf_bwd": (_i, [_p, _l, _p, _l, _i, _p, _p, _l, _p, _p, _p, _p, _p]),
     "ctr_linear_fwd": (_i, [_p, _l, _p, _l, _p, _p, _l, _p, _l, _l, _i, _i, _i, _p]),
     "ctr_linear_bwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _p, _l, _i, _p, _l, _p, _l, _i, _i, _i, _p]),
+    "ctr_allpairs_fwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _p]),
+    "ctr_allpairs_bwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _p, _l, _i, _p]),
+    "ctr_fm_wide_fwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _p, _l, _p, _p]),
+    "ctr_fm_wide_bwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _p, _l,
+                             _p, _p, _p, _p, _p, _l, _i, _p]),
+    "ctr_ffm_head_fwd": (_i, [_p, _l, _l, _i, _i, C.POINTER(C.c_int32), _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l,
+                              _p, _p, _p, _l, _p, _p]),
+    "ctr_ffm_head_bwd": (_i, [_p, _l, _l, _i, _i, C.POINTER(C.c_int32), _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l,
+                              _p, _p, _p, _l, _p, _l, _p, _p, _p, _p, _p, _l, _p]),
+    "ctr_act_bwd": (_i, [_p, _l, _p, _l, _p, _l, _l, _i, _i, _i, _p]),
 }
 
 _lock = threading.Lock()

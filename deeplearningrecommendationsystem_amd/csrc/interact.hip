@@ -1,0 +1,629 @@
+// Feature-interaction kernels on the stacked embedding matrix emb (B, nvec*E) that
+// the embedding stage wrote: PNN inner products, the DeepFM wide + FM second-order
+// term, the FFM field-aware cross + logistic head, and the small elementwise
+// activation backward the residual blocks need.  All are HBM-bound per-sample
+// reductions: a workgroup stages a tile of samples in LDS (vectors padded so that
+// lanes reading different vectors at the same offset hit different banks), reduces
+// there, and writes coalesced results.  No MFMA by design.
+#include "ctr_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kLdsFloats = 12288;  // 48 KiB of staged vectors per workgroup
+constexpr int kMaxPairs = 64;      // explicit pair list (FFM uses 15)
+constexpr int kMaxDense = 64;      // dense feature columns of the LR part (43 in the zoo)
+
+struct Geometry {
+  int nvec, e, vec, estride, row;  // row = floats per staged sample
+  int tb;                          // samples per tile
+};
+
+inline Geometry make_geometry(int nvec, int e, bool aligned, int extra_per_sample = 0) {
+  Geometry g;
+  g.nvec = nvec;
+  g.e = e;
+  g.vec = (aligned && e % 4 == 0) ? 4 : 1;
+  g.estride = g.vec == 4 ? e + 4 : e + 1;
+  g.row = nvec * g.estride;
+  int tb = kLdsFloats / (g.row + extra_per_sample);
+  if (tb > 64) tb = 64;
+  g.tb = tb;
+  return g;
+}
+
+template <int VEC>
+__device__ __forceinline__ void stage_vectors(float* lds, const Geometry& g, const float* __restrict__ emb, int64_t lde,
+                                              int64_t b0, int count) {
+  const int chunks = g.e / VEC;
+  const int per_sample = g.nvec * chunks;
+  for (int i = threadIdx.x; i < count * per_sample; i += blockDim.x) {
+    const int s = i / per_sample, rem = i - s * per_sample;
+    const int f = rem / chunks, c = rem - f * chunks;
+    const float* src = emb + (b0 + s) * lde + f * g.e + c * VEC;
+    float* dst = lds + s * g.row + f * g.estride + c * VEC;
+    if (VEC == 4)
+      *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+    else
+      *dst = *src;
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ float dot_lds(const float* a, const float* b, int e) {
+  float acc = 0.0f;
+  if (VEC == 4) {
+    for (int k = 0; k < e; k += 4) {
+      const float4 x = *reinterpret_cast<const float4*>(a + k);
+      const float4 y = *reinterpret_cast<const float4*>(b + k);
+      acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+    }
+  } else {
+    for (int k = 0; k < e; ++k) acc = fmaf(a[k], b[k], acc);
+  }
+  return acc;
+}
+
+// ------------------------------------------------------------------ PNN inner
+// p[b, idx(i,j)] = <v_i, v_j>, i < j lexicographic (model/pnn.py:59-66)
+__device__ __forceinline__ int pair_index(int i, int j, int n) { return i * n - i * (i + 1) / 2 + (j - i - 1); }
+
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+allpairs_fwd_kernel(const Geometry g, const float* __restrict__ emb, int64_t lde, int64_t batch,
+                    float* __restrict__ out, int64_t ldo) {
+  extern __shared__ float lds[];
+  const int npairs = g.nvec * (g.nvec - 1) / 2;
+  for (int64_t b0 = (int64_t)blockIdx.x * g.tb; b0 < batch; b0 += (int64_t)gridDim.x * g.tb) {
+    const int count = (int)(batch - b0 < g.tb ? batch - b0 : g.tb);
+    stage_vectors<VEC>(lds, g, emb, lde, b0, count);
+    __syncthreads();
+    for (int w = threadIdx.x; w < count * npairs; w += blockDim.x) {
+      const int s = w / npairs, p = w - s * npairs;
+      // invert pair_index: walk the rows of the strict upper triangle
+      int i = 0, rem = p;
+      while (rem >= g.nvec - 1 - i) { rem -= g.nvec - 1 - i; ++i; }
+      const int j = i + 1 + rem;
+      const float* base = lds + s * g.row;
+      out[(b0 + s) * ldo + p] = dot_lds<VEC>(base + i * g.estride, base + j * g.estride, g.e);
+    }
+    __syncthreads();
+  }
+}
+
+// gemb[b, i, :] (+)= sum_{j != i} gp[b, idx(i,j)] * v_j
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+allpairs_bwd_kernel(const Geometry g, const float* __restrict__ emb, int64_t lde, int64_t batch,
+                    const float* __restrict__ gp, int64_t ldgp, float* __restrict__ gemb, int64_t ldg,
+                    int accumulate) {
+  extern __shared__ float lds[];
+  const int npairs = g.nvec * (g.nvec - 1) / 2;
+  float* s_gp = lds + g.tb * g.row;  // [tb][npairs]
+  const int chunks = g.e / VEC;
+  for (int64_t b0 = (int64_t)blockIdx.x * g.tb; b0 < batch; b0 += (int64_t)gridDim.x * g.tb) {
+    const int count = (int)(batch - b0 < g.tb ? batch - b0 : g.tb);
+    stage_vectors<VEC>(lds, g, emb, lde, b0, count);
+    for (int w = threadIdx.x; w < count * npairs; w += blockDim.x) {
+      const int s = w / npairs, p = w - s * npairs;
+      s_gp[s * npairs + p] = gp[(b0 + s) * ldgp + p];
+    }
+    __syncthreads();
+    const int per_sample = g.nvec * chunks;
+    for (int w = threadIdx.x; w < count * per_sample; w += blockDim.x) {
+      const int s = w / per_sample, rem = w - s * per_sample;
+      const int i = rem / chunks, c = (rem - i * chunks) * VEC;
+      const float* base = lds + s * g.row;
+      const float* gps = s_gp + s * npairs;
+      float acc[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
+      for (int j = 0; j < g.nvec; ++j) {
+        if (j == i) continue;
+        const float coef = gps[j > i ? pair_index(i, j, g.nvec) : pair_index(j, i, g.nvec)];
+        const float* vj = base + j * g.estride + c;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = fmaf(coef, vj[v], acc[v]);
+      }
+      float* dst = gemb + (b0 + s) * ldg + i * g.e + c;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) dst[v] = accumulate ? dst[v] + acc[v] : acc[v];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------- logistic ("wide") part shared
+struct WideArgs {
+  const float* x;        // (B, ldx) feature matrix
+  int64_t ldx;
+  int user_col, item_col, dense_col0, ndense;
+  const float* user1;    // (num_users, 1)
+  const float* item1;    // (num_items, 1)
+  int64_t num_users, num_items;
+  const float* w;        // (ndense) weight of the dense columns
+  const float* b;        // (1)
+};
+
+struct WideGrads {
+  float* user1;
+  float* item1;
+  float* w;
+  float* b;
+};
+
+__device__ __forceinline__ int64_t clamp_row(float v, int64_t n, int32_t* err) {
+  int64_t r = (int64_t)v;
+  if (r < 0 || r >= n) {
+    if (err) *err = 1;
+    r = 0;
+  }
+  return r;
+}
+
+// -------------------------------------------------------------- DeepFM wide + FM
+// out[b] = ((user1[u] + item1[i]) + (x[b,dense] . w + wb)) + 0.5 * sum_e[(sum_f v)^2 - sum_f v^2]
+// (model/deepfm.py:63, 71-77)
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+fm_wide_fwd_kernel(const Geometry g, const float* __restrict__ emb, int64_t lde, int64_t batch, const WideArgs a,
+                   float* __restrict__ out, int64_t ldo, int32_t* err) {
+  extern __shared__ float lds[];
+  float* s_part = lds + g.tb * g.row;  // [tb][chunks] partial FM sums
+  const int chunks = g.e / VEC;
+  for (int64_t b0 = (int64_t)blockIdx.x * g.tb; b0 < batch; b0 += (int64_t)gridDim.x * g.tb) {
+    const int count = (int)(batch - b0 < g.tb ? batch - b0 : g.tb);
+    stage_vectors<VEC>(lds, g, emb, lde, b0, count);
+    __syncthreads();
+    for (int w = threadIdx.x; w < count * chunks; w += blockDim.x) {
+      const int s = w / chunks, c = (w - s * chunks) * VEC;
+      const float* base = lds + s * g.row + c;
+      float part = 0.0f;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        float sum = 0.0f, sq = 0.0f;
+        for (int f = 0; f < g.nvec; ++f) {
+          const float t = base[f * g.estride + v];
+          sum += t;
+          sq = fmaf(t, t, sq);
+        }
+        part += sum * sum - sq;
+      }
+      s_part[s * chunks + (c / VEC)] = part;
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < count; s += blockDim.x) {
+      float cross = 0.0f;
+      for (int c = 0; c < chunks; ++c) cross += s_part[s * chunks + c];
+      cross *= 0.5f;
+      const float* xr = a.x + (b0 + s) * a.ldx;
+      const int64_t u = clamp_row(xr[a.user_col], a.num_users, err);
+      const int64_t i = clamp_row(xr[a.item_col], a.num_items, err);
+      float lin = 0.0f;
+      for (int c = 0; c < a.ndense; ++c) lin = fmaf(xr[a.dense_col0 + c], a.w[c], lin);
+      lin += a.b[0];
+      out[(b0 + s) * ldo] = ((a.user1[u] + a.item1[i]) + lin) + cross;
+    }
+    __syncthreads();
+  }
+}
+
+// backward of the above for g = gout[b]:
+//   user1[u] += g, item1[i] += g, w[c] += sum_b g x[b,c], b += sum_b g,
+//   gemb[b,f,e] (+)= g * (S_e - v_fe)
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+fm_wide_bwd_kernel(const Geometry g, const float* __restrict__ emb, int64_t lde, int64_t batch, const WideArgs a,
+                   const float* __restrict__ gout, int64_t ldgo, const WideGrads wg, float* __restrict__ gemb,
+                   int64_t ldg, int accumulate) {
+  extern __shared__ float lds[];
+  __shared__ float s_w[kMaxDense + 1];  // block-level sums for w and b
+  float* s_g = lds + g.tb * g.row;      // [tb]
+  const int chunks = g.e / VEC;
+  for (int i = threadIdx.x; i <= a.ndense; i += blockDim.x) s_w[i] = 0.0f;
+  for (int64_t b0 = (int64_t)blockIdx.x * g.tb; b0 < batch; b0 += (int64_t)gridDim.x * g.tb) {
+    const int count = (int)(batch - b0 < g.tb ? batch - b0 : g.tb);
+    stage_vectors<VEC>(lds, g, emb, lde, b0, count);
+    for (int s = threadIdx.x; s < count; s += blockDim.x) s_g[s] = gout[(b0 + s) * ldgo];
+    __syncthreads();
+    // per-sample scalars: id tables
+    for (int s = threadIdx.x; s < count; s += blockDim.x) {
+      const float gv = s_g[s];
+      const float* xr = a.x + (b0 + s) * a.ldx;
+      int64_t u = (int64_t)xr[a.user_col], i = (int64_t)xr[a.item_col];
+      if (u < 0 || u >= a.num_users) u = 0;
+      if (i < 0 || i >= a.num_items) i = 0;
+      if (wg.user1) unsafeAtomicAdd(wg.user1 + u, gv);
+      if (wg.item1) unsafeAtomicAdd(wg.item1 + i, gv);
+    }
+    // dense weights: thread c sums g*x over the tile (sequential over samples: fixed order)
+    if (wg.w || wg.b) {
+      for (int c = threadIdx.x; c <= a.ndense; c += blockDim.x) {
+        float acc = 0.0f;
+        for (int s = 0; s < count; ++s) {
+          const float xv = c < a.ndense ? a.x[(b0 + s) * a.ldx + a.dense_col0 + c] : 1.0f;
+          acc = fmaf(s_g[s], xv, acc);
+        }
+        s_w[c] += acc;
+      }
+    }
+    // FM second-order gradient
+    if (gemb) {
+      const int per_sample = g.nvec * chunks;
+      for (int w = threadIdx.x; w < count * per_sample; w += blockDim.x) {
+        const int s = w / per_sample, rem = w - s * per_sample;
+        const int f = rem / chunks, c = (rem - f * chunks) * VEC;
+        const float* base = lds + s * g.row + c;
+        float* dst = gemb + (b0 + s) * ldg + f * g.e + c;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          float sum = 0.0f;
+          for (int ff = 0; ff < g.nvec; ++ff) sum += base[ff * g.estride + v];
+          const float val = s_g[s] * (sum - base[f * g.estride + v]);
+          dst[v] = accumulate ? dst[v] + val : val;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c <= a.ndense; c += blockDim.x) {
+    const float v = s_w[c];
+    if (c < a.ndense) {
+      if (wg.w && v != 0.0f) unsafeAtomicAdd(wg.w + c, v);
+    } else if (wg.b && v != 0.0f) {
+      unsafeAtomicAdd(wg.b, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- FFM head
+struct PairList {
+  int n;
+  unsigned char a[kMaxPairs];
+  unsigned char b[kMaxPairs];
+};
+
+// prob[b] = sigmoid(user1[u] + item1[i] + sum_c (x[b,c] + cross) w[c] + wb),
+// cross = sum_p <v_a(p), v_b(p)> added left to right (model/ffm.py:62-86; the
+// cross scalar is added to every dense input before the linear layer, as there)
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+ffm_head_fwd_kernel(const Geometry g, const float* __restrict__ emb, int64_t lde, int64_t batch, const PairList pl,
+                    const WideArgs a, float* __restrict__ prob, int64_t ldo, int32_t* err) {
+  extern __shared__ float lds[];
+  float* s_dot = lds + g.tb * g.row;  // [tb][npairs]
+  for (int64_t b0 = (int64_t)blockIdx.x * g.tb; b0 < batch; b0 += (int64_t)gridDim.x * g.tb) {
+    const int count = (int)(batch - b0 < g.tb ? batch - b0 : g.tb);
+    stage_vectors<VEC>(lds, g, emb, lde, b0, count);
+    __syncthreads();
+    for (int w = threadIdx.x; w < count * pl.n; w += blockDim.x) {
+      const int s = w / pl.n, p = w - s * pl.n;
+      const float* base = lds + s * g.row;
+      s_dot[s * pl.n + p] = dot_lds<VEC>(base + pl.a[p] * g.estride, base + pl.b[p] * g.estride, g.e);
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < count; s += blockDim.x) {
+      float cross = s_dot[s * pl.n];
+      for (int p = 1; p < pl.n; ++p) cross += s_dot[s * pl.n + p];
+      const float* xr = a.x + (b0 + s) * a.ldx;
+      const int64_t u = clamp_row(xr[a.user_col], a.num_users, err);
+      const int64_t i = clamp_row(xr[a.item_col], a.num_items, err);
+      float lin = 0.0f;
+      for (int c = 0; c < a.ndense; ++c) lin = fmaf(xr[a.dense_col0 + c] + cross, a.w[c], lin);
+      lin += a.b[0];
+      prob[(b0 + s) * ldo] = ctr_sigmoid((a.user1[u] + a.item1[i]) + lin);
+    }
+    __syncthreads();
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+ffm_head_bwd_kernel(const Geometry g, const float* __restrict__ emb, int64_t lde, int64_t batch, const PairList pl,
+                    const WideArgs a, const float* __restrict__ prob, int64_t ldp, const float* __restrict__ gprob,
+                    int64_t ldgp, const WideGrads wg, float* __restrict__ gemb, int64_t ldg) {
+  extern __shared__ float lds[];
+  __shared__ float s_w[kMaxDense + 1];
+  __shared__ float s_wsum;
+  float* s_dot = lds + g.tb * g.row;      // [tb][npairs] then reused
+  float* s_dz = s_dot + g.tb * pl.n;      // [tb] dlogit
+  float* s_cross = s_dz + g.tb;           // [tb]
+  const int chunks = g.e / VEC;
+  for (int i = threadIdx.x; i <= a.ndense; i += blockDim.x) s_w[i] = 0.0f;
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+    for (int c = 0; c < a.ndense; ++c) t += a.w[c];
+    s_wsum = t;
+  }
+  for (int64_t b0 = (int64_t)blockIdx.x * g.tb; b0 < batch; b0 += (int64_t)gridDim.x * g.tb) {
+    const int count = (int)(batch - b0 < g.tb ? batch - b0 : g.tb);
+    stage_vectors<VEC>(lds, g, emb, lde, b0, count);
+    __syncthreads();
+    for (int w = threadIdx.x; w < count * pl.n; w += blockDim.x) {
+      const int s = w / pl.n, p = w - s * pl.n;
+      const float* base = lds + s * g.row;
+      s_dot[s * pl.n + p] = dot_lds<VEC>(base + pl.a[p] * g.estride, base + pl.b[p] * g.estride, g.e);
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < count; s += blockDim.x) {
+      float cross = s_dot[s * pl.n];
+      for (int p = 1; p < pl.n; ++p) cross += s_dot[s * pl.n + p];
+      const float pv = prob[(b0 + s) * ldp];
+      const float dz = gprob[(b0 + s) * ldgp] * pv * (1.0f - pv);
+      s_dz[s] = dz;
+      s_cross[s] = cross;
+      const float* xr = a.x + (b0 + s) * a.ldx;
+      int64_t u = (int64_t)xr[a.user_col], i = (int64_t)xr[a.item_col];
+      if (u < 0 || u >= a.num_users) u = 0;
+      if (i < 0 || i >= a.num_items) i = 0;
+      if (wg.user1) unsafeAtomicAdd(wg.user1 + u, dz);
+      if (wg.item1) unsafeAtomicAdd(wg.item1 + i, dz);
+    }
+    __syncthreads();
+    if (wg.w || wg.b) {
+      for (int c = threadIdx.x; c <= a.ndense; c += blockDim.x) {
+        float acc = 0.0f;
+        for (int s = 0; s < count; ++s) {
+          const float xv = c < a.ndense ? a.x[(b0 + s) * a.ldx + a.dense_col0 + c] + s_cross[s] : 1.0f;
+          acc = fmaf(s_dz[s], xv, acc);
+        }
+        s_w[c] += acc;
+      }
+    }
+    if (gemb) {
+      const int per_sample = g.nvec * chunks;
+      for (int w = threadIdx.x; w < count * per_sample; w += blockDim.x) {
+        const int s = w / per_sample, rem = w - s * per_sample;
+        const int f = rem / chunks, c = (rem - f * chunks) * VEC;
+        const float* base = lds + s * g.row + c;
+        const float dcross = s_dz[s] * s_wsum;
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
+        for (int p = 0; p < pl.n; ++p) {
+          int other = -1;
+          if (pl.a[p] == f) other = pl.b[p];
+          else if (pl.b[p] == f) other = pl.a[p];
+          if (other >= 0) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] += base[other * g.estride + v];
+          }
+        }
+        float* dst = gemb + (b0 + s) * ldg + f * g.e + c;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) dst[v] = dcross * acc[v];
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c <= a.ndense; c += blockDim.x) {
+    const float v = s_w[c];
+    if (c < a.ndense) {
+      if (wg.w && v != 0.0f) unsafeAtomicAdd(wg.w + c, v);
+    } else if (wg.b && v != 0.0f) {
+      unsafeAtomicAdd(wg.b, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------ activation bwd
+__global__ void __launch_bounds__(kBlock)
+act_bwd_kernel(const float* __restrict__ y, int64_t ldy, const float* __restrict__ gy, int64_t ldgy,
+               float* __restrict__ out, int64_t ldo, int64_t m, int n, int act, int accumulate) {
+  const int64_t total = m * n;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / n;
+    const int c = (int)(t - r * n);
+    const float v = gy[r * ldgy + c] * ctr_act_grad(y[r * ldy + c], act);
+    float* dst = out + r * ldo + c;
+    *dst = accumulate ? *dst + v : v;
+  }
+}
+
+int check_wide(const WideArgs& a) {
+  CTR_REQUIRE(a.x && a.ldx > 0 && a.user1 && a.item1 && a.w && a.b, CTR_EINVAL);
+  CTR_REQUIRE(a.num_users > 0 && a.num_items > 0, CTR_EINVAL);
+  CTR_REQUIRE(a.ndense > 0 && a.ndense <= kMaxDense, CTR_ELIMIT);
+  CTR_REQUIRE(a.user_col >= 0 && a.item_col >= 0 && a.dense_col0 >= 0 && a.dense_col0 + a.ndense <= a.ldx &&
+                  a.user_col < a.ldx && a.item_col < a.ldx,
+              CTR_EINVAL);
+  return CTR_OK;
+}
+
+inline int tile_grid(int64_t batch, int tb) {
+  int64_t tiles = ctr_ceil_div(batch, tb);
+  return (int)(tiles < 2048 ? tiles : 2048);
+}
+
+}  // namespace
+
+extern "C" int ctr_allpairs_fwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim, float* out,
+                                int64_t ldo, void* stream) {
+  CTR_REQUIRE(batch >= 0, CTR_EINVAL);
+  if (batch == 0) return CTR_OK;
+  CTR_REQUIRE(emb && out && nvec >= 2 && nvec <= 32 && dim > 0, CTR_EINVAL);
+  CTR_REQUIRE(lde >= (int64_t)nvec * dim && ldo >= nvec * (nvec - 1) / 2, CTR_EINVAL);
+  const Geometry g = make_geometry(nvec, dim, ctr_aligned16(emb) && lde % 4 == 0);
+  CTR_REQUIRE(g.tb >= 1, CTR_ELIMIT);
+  const size_t dyn = (size_t)g.tb * g.row * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (g.vec == 4)
+    hipLaunchKernelGGL(allpairs_fwd_kernel<4>, dim3(tile_grid(batch, g.tb)), dim3(kBlock), dyn, st, g, emb, lde, batch,
+                       out, ldo);
+  else
+    hipLaunchKernelGGL(allpairs_fwd_kernel<1>, dim3(tile_grid(batch, g.tb)), dim3(kBlock), dyn, st, g, emb, lde, batch,
+                       out, ldo);
+  return ctr_launch_status();
+}
+
+extern "C" int ctr_allpairs_bwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim, const float* gp,
+                                int64_t ldgp, float* gemb, int64_t ldg, int accumulate, void* stream) {
+  CTR_REQUIRE(batch >= 0, CTR_EINVAL);
+  if (batch == 0) return CTR_OK;
+  CTR_REQUIRE(emb && gp && gemb && nvec >= 2 && nvec <= 32 && dim > 0, CTR_EINVAL);
+  const int npairs = nvec * (nvec - 1) / 2;
+  CTR_REQUIRE(lde >= (int64_t)nvec * dim && ldg >= (int64_t)nvec * dim && ldgp >= npairs, CTR_EINVAL);
+  const Geometry g = make_geometry(nvec, dim, ctr_aligned16(emb) && lde % 4 == 0, npairs);
+  CTR_REQUIRE(g.tb >= 1, CTR_ELIMIT);
+  const size_t dyn = (size_t)g.tb * (g.row + npairs) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (g.vec == 4)
+    hipLaunchKernelGGL(allpairs_bwd_kernel<4>, dim3(tile_grid(batch, g.tb)), dim3(kBlock), dyn, st, g, emb, lde, batch,
+                       gp, ldgp, gemb, ldg, accumulate);
+  else
+    hipLaunchKernelGGL(allpairs_bwd_kernel<1>, dim3(tile_grid(batch, g.tb)), dim3(kBlock), dyn, st, g, emb, lde, batch,
+                       gp, ldgp, gemb, ldg, accumulate);
+  return ctr_launch_status();
+}
+
+static WideArgs wide_args(const float* x, int64_t ldx, int user_col, int item_col, int dense_col0, int ndense,
+                          const float* user1, int64_t num_users, const float* item1, int64_t num_items,
+                          const float* w, const float* b) {
+  WideArgs a;
+  a.x = x; a.ldx = ldx; a.user_col = user_col; a.item_col = item_col; a.dense_col0 = dense_col0; a.ndense = ndense;
+  a.user1 = user1; a.item1 = item1; a.num_users = num_users; a.num_items = num_items; a.w = w; a.b = b;
+  return a;
+}
+
+extern "C" int ctr_fm_wide_fwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim, const float* x,
+                               int64_t ldx, int user_col, int item_col, int dense_col0, int ndense,
+                               const float* user1, int64_t num_users, const float* item1, int64_t num_items,
+                               const float* wide_w, const float* wide_b, float* out, int64_t ldo, int32_t* err_flag,
+                               void* stream) {
+  CTR_REQUIRE(batch >= 0, CTR_EINVAL);
+  if (batch == 0) return CTR_OK;
+  CTR_REQUIRE(emb && out && nvec >= 1 && nvec <= 64 && dim > 0 && ldo >= 1 && lde >= (int64_t)nvec * dim, CTR_EINVAL);
+  const WideArgs a = wide_args(x, ldx, user_col, item_col, dense_col0, ndense, user1, num_users, item1, num_items,
+                               wide_w, wide_b);
+  int rc = check_wide(a);
+  if (rc != CTR_OK) return rc;
+  const bool al = ctr_aligned16(emb) && lde % 4 == 0;
+  const int chunks = (al && dim % 4 == 0) ? dim / 4 : dim;
+  const Geometry g = make_geometry(nvec, dim, al, chunks);
+  CTR_REQUIRE(g.tb >= 1, CTR_ELIMIT);
+  const size_t dyn = (size_t)g.tb * (g.row + chunks) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (g.vec == 4)
+    hipLaunchKernelGGL(fm_wide_fwd_kernel<4>, dim3(tile_grid(batch, g.tb)), dim3(kBlock), dyn, st, g, emb, lde, batch, a,
+                       out, ldo, err_flag);
+  else
+    hipLaunchKernelGGL(fm_wide_fwd_kernel<1>, dim3(tile_grid(batch, g.tb)), dim3(kBlock), dyn, st, g, emb, lde, batch, a,
+                       out, ldo, err_flag);
+  return ctr_launch_status();
+}
+
+extern "C" int ctr_fm_wide_bwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim, const float* x,
+                               int64_t ldx, int user_col, int item_col, int dense_col0, int ndense,
+                               const float* user1, int64_t num_users, const float* item1, int64_t num_items,
+                               const float* wide_w, const float* wide_b, const float* gout, int64_t ldgo,
+                               float* guser1, float* gitem1, float* gwide_w, float* gwide_b, float* gemb, int64_t ldg,
+                               int accumulate, void* stream) {
+  CTR_REQUIRE(batch >= 0, CTR_EINVAL);
+  if (batch == 0) return CTR_OK;
+  CTR_REQUIRE(emb && gout && nvec >= 1 && nvec <= 64 && dim > 0 && ldgo >= 1 && lde >= (int64_t)nvec * dim, CTR_EINVAL);
+  CTR_REQUIRE(!gemb || ldg >= (int64_t)nvec * dim, CTR_EINVAL);
+  const WideArgs a = wide_args(x, ldx, user_col, item_col, dense_col0, ndense, user1, num_users, item1, num_items,
+                               wide_w, wide_b);
+  int rc = check_wide(a);
+  if (rc != CTR_OK) return rc;
+  const Geometry g = make_geometry(nvec, dim, ctr_aligned16(emb) && lde % 4 == 0, 1);
+  CTR_REQUIRE(g.tb >= 1, CTR_ELIMIT);
+  const size_t dyn = (size_t)g.tb * (g.row + 1) * sizeof(float);
+  const WideGrads wg{guser1, gitem1, gwide_w, gwide_b};
+  int grid = tile_grid(batch, g.tb);
+  if (grid > 1024) grid = 1024;  // each block ends with ndense+1 global atomics
+  hipStream_t st = (hipStream_t)stream;
+  if (g.vec == 4)
+    hipLaunchKernelGGL(fm_wide_bwd_kernel<4>, dim3(grid), dim3(kBlock), dyn, st, g, emb, lde, batch, a, gout, ldgo, wg,
+                       gemb, ldg, accumulate);
+  else
+    hipLaunchKernelGGL(fm_wide_bwd_kernel<1>, dim3(grid), dim3(kBlock), dyn, st, g, emb, lde, batch, a, gout, ldgo, wg,
+                       gemb, ldg, accumulate);
+  return ctr_launch_status();
+}
+
+static int make_pairs(const int32_t* pairs, int npairs, int nvec, PairList* pl) {
+  CTR_REQUIRE(pairs && npairs >= 1 && npairs <= kMaxPairs, CTR_ELIMIT);
+  pl->n = npairs;
+  for (int p = 0; p < npairs; ++p) {
+    const int a = pairs[2 * p], b = pairs[2 * p + 1];
+    CTR_REQUIRE(a >= 0 && a < nvec && b >= 0 && b < nvec && a != b, CTR_EINVAL);
+    pl->a[p] = (unsigned char)a;
+    pl->b[p] = (unsigned char)b;
+  }
+  return CTR_OK;
+}
+
+extern "C" int ctr_ffm_head_fwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim,
+                                const int32_t* pairs /*host, 2*npairs*/, int npairs, const float* x, int64_t ldx,
+                                int user_col, int item_col, int dense_col0, int ndense, const float* user1,
+                                int64_t num_users, const float* item1, int64_t num_items, const float* lin_w,
+                                const float* lin_b, float* prob, int64_t ldo, int32_t* err_flag, void* stream) {
+  CTR_REQUIRE(batch >= 0, CTR_EINVAL);
+  if (batch == 0) return CTR_OK;
+  CTR_REQUIRE(emb && prob && nvec >= 2 && nvec <= 64 && dim > 0 && ldo >= 1 && lde >= (int64_t)nvec * dim, CTR_EINVAL);
+  PairList pl;
+  int rc = make_pairs(pairs, npairs, nvec, &pl);
+  if (rc != CTR_OK) return rc;
+  const WideArgs a = wide_args(x, ldx, user_col, item_col, dense_col0, ndense, user1, num_users, item1, num_items,
+                               lin_w, lin_b);
+  rc = check_wide(a);
+  if (rc != CTR_OK) return rc;
+  const Geometry g = make_geometry(nvec, dim, ctr_aligned16(emb) && lde % 4 == 0, npairs);
+  CTR_REQUIRE(g.tb >= 1, CTR_ELIMIT);
+  const size_t dyn = (size_t)g.tb * (g.row + npairs) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (g.vec == 4)
+    hipLaunchKernelGGL(ffm_head_fwd_kernel<4>, dim3(tile_grid(batch, g.tb)), dim3(kBlock), dyn, st, g, emb, lde, batch,
+                       pl, a, prob, ldo, err_flag);
+  else
+    hipLaunchKernelGGL(ffm_head_fwd_kernel<1>, dim3(tile_grid(batch, g.tb)), dim3(kBlock), dyn, st, g, emb, lde, batch,
+                       pl, a, prob, ldo, err_flag);
+  return ctr_launch_status();
+}
+
+extern "C" int ctr_ffm_head_bwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim, const int32_t* pairs,
+                                int npairs, const float* x, int64_t ldx, int user_col, int item_col, int dense_col0,
+                                int ndense, const float* user1, int64_t num_users, const float* item1,
+                                int64_t num_items, const float* lin_w, const float* lin_b, const float* prob,
+                                int64_t ldp, const float* gprob, int64_t ldgp, float* guser1, float* gitem1,
+                                float* glin_w, float* glin_b, float* gemb, int64_t ldg, void* stream) {
+  CTR_REQUIRE(batch >= 0, CTR_EINVAL);
+  if (batch == 0) return CTR_OK;
+  CTR_REQUIRE(emb && prob && gprob && nvec >= 2 && nvec <= 64 && dim > 0 && lde >= (int64_t)nvec * dim, CTR_EINVAL);
+  CTR_REQUIRE(ldp >= 1 && ldgp >= 1 && (!gemb || ldg >= (int64_t)nvec * dim), CTR_EINVAL);
+  PairList pl;
+  int rc = make_pairs(pairs, npairs, nvec, &pl);
+  if (rc != CTR_OK) return rc;
+  const WideArgs a = wide_args(x, ldx, user_col, item_col, dense_col0, ndense, user1, num_users, item1, num_items,
+                               lin_w, lin_b);
+  rc = check_wide(a);
+  if (rc != CTR_OK) return rc;
+  const Geometry g = make_geometry(nvec, dim, ctr_aligned16(emb) && lde % 4 == 0, npairs + 2);
+  CTR_REQUIRE(g.tb >= 1, CTR_ELIMIT);
+  const size_t dyn = (size_t)g.tb * (g.row + npairs + 2) * sizeof(float);
+  const WideGrads wg{guser1, gitem1, glin_w, glin_b};
+  int grid = tile_grid(batch, g.tb);
+  if (grid > 1024) grid = 1024;
+  hipStream_t st = (hipStream_t)stream;
+  if (g.vec == 4)
+    hipLaunchKernelGGL(ffm_head_bwd_kernel<4>, dim3(grid), dim3(kBlock), dyn, st, g, emb, lde, batch, pl, a, prob, ldp,
+                       gprob, ldgp, wg, gemb, ldg);
+  else
+    hipLaunchKernelGGL(ffm_head_bwd_kernel<1>, dim3(grid), dim3(kBlock), dyn, st, g, emb, lde, batch, pl, a, prob, ldp,
+                       gprob, ldgp, wg, gemb, ldg);
+  return ctr_launch_status();
+}
+
+extern "C" int ctr_act_bwd(const float* y, int64_t ldy, const float* gy, int64_t ldgy, float* out, int64_t ldo,
+                           int64_t m, int n, int act, int accumulate, void* stream) {
+  CTR_REQUIRE(m >= 0 && n > 0, CTR_EINVAL);
+  if (m == 0) return CTR_OK;
+  CTR_REQUIRE(y && gy && out && ldy >= n && ldgy >= n && ldo >= n, CTR_EINVAL);
+  CTR_REQUIRE(act >= CTR_ACT_NONE && act <= CTR_ACT_SIGMOID, CTR_EINVAL);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ctr_stream_grid(m * n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, y, ldy,
+                     gy, ldgy, out, ldo, m, n, act, accumulate);
+  return ctr_launch_status();
+}

@@ -3,5 +3,9 @@ names, constructor arguments, parameter names (state_dict keys) and ``forward``
 signatures; forward/backward run on libctrhip's gfx950 kernels."""
 from .mf import MatrixFactorization
 from .neuralcf import NeuralCF
+from .deepfm import DeepFM
+from .pnn import PNN
+from .ffm import FFM
+from .deepcrossing import DeepCrossing
 
-__all__ = ["MatrixFactorization", "NeuralCF"]
+__all__ = ["MatrixFactorization", "NeuralCF", "DeepFM", "PNN", "FFM", "DeepCrossing"]

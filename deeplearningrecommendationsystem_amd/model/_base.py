@@ -41,3 +41,52 @@ class CtrModule(nn.Module):
 
 def topk_rows(scores: torch.Tensor, k: int) -> np.ndarray:
     return torch.topk(scores, k, dim=-1).indices.cpu().numpy()
+
+
+class _ModelFunction(torch.autograd.Function):
+    """one autograd node per model: ``impl.run_forward(inputs, params)`` returns
+    ``(output, state)``; ``impl.run_backward(state, inputs, params, gout)``
+    returns one gradient (or None) per parameter.  Forward and backward are
+    straight sequences of libctrhip launches on torch's current stream."""
+
+    @staticmethod
+    def forward(ctx, impl, n_inputs, *tensors):
+        inputs, params = tensors[:n_inputs], tensors[n_inputs:]
+        out, state = impl.run_forward(inputs, params)
+        ctx.impl, ctx.state, ctx.n_inputs = impl, state, n_inputs
+        ctx.save_for_backward(*tensors)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        tensors = ctx.saved_tensors
+        inputs, params = tensors[:ctx.n_inputs], tensors[ctx.n_inputs:]
+        grads = ctx.impl.run_backward(ctx.state, inputs, params, gout.contiguous())
+        ctx.state = None
+        return (None, None) + (None,) * ctx.n_inputs + tuple(grads)
+
+
+class FeatureModel(CtrModule):
+    """models fed by the (B,45) float feature matrix of data/reader.py:98-112"""
+
+    def _run_model(self, x, params):
+        self._need_device(x, params[0])
+        if x.dim() != 2 or x.shape[1] != 45 or x.dtype != torch.float32:
+            raise ValueError(f"expected a (B,45) float32 feature matrix, got {tuple(x.shape)} {x.dtype}")
+        x = x if x.stride(1) == 1 else x.contiguous()
+        object.__setattr__(self, "_flag", self._err_flag(x.device))
+        out = _ModelFunction.apply(self, 1, x, *params)
+        self._raise_if_bad_index()
+        return out
+
+    def _rank_users(self, num_users, user_item, k):
+        """reference recommendation(): per-user scoring of the rows of the pandas
+        frame ``user_item`` (e.g. model/pnn.py:133-143)"""
+        rows = []
+        dev = next(self.parameters()).device
+        with torch.no_grad():
+            for u in range(num_users):
+                feats = torch.tensor(user_item[user_item['user_id'] == u].values, dtype=torch.float32, device=dev)
+                scores = self.forward(feats)
+                rows.append(torch.topk(scores, k, dim=0).indices.view(1, -1).tolist()[0])
+        return np.array(rows)

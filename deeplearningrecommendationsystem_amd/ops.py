@@ -295,3 +295,99 @@ def mlp_bwd(acts: Sequence[torch.Tensor], layers: Sequence[Layer], gy: torch.Ten
         grads[k] = (gw, gb)
         g = gx
     return grads, g
+
+
+# ---------------------------------------------------------------------------
+# feature interactions
+# ---------------------------------------------------------------------------
+USER_COL, ITEM_COL, DENSE_COL0, NUM_DENSE = 0, 1, 2, 43  # the (B,45) layout of data/reader.py:98-112
+
+
+def allpairs_fwd(emb: torch.Tensor, nvec: int, dim: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    emb = _mat(emb, "emb")
+    batch = emb.shape[0]
+    npairs = nvec * (nvec - 1) // 2
+    if out is None:
+        out = torch.empty((batch, npairs), dtype=torch.float32, device=emb.device)
+    rc = _timed("allpairs_fwd", lambda: (4 * batch * (nvec * dim + npairs), 2 * batch * npairs * dim),
+                _lib.load().ctr_allpairs_fwd, emb.data_ptr(), _ld(emb), batch, nvec, dim, out.data_ptr(), _ld(out),
+                _lib.stream_ptr())
+    _lib.check(rc, "ctr_allpairs_fwd")
+    return out
+
+
+def allpairs_bwd(emb, nvec, dim, gp, gemb, accumulate: bool) -> None:
+    emb, gp, gemb = _mat(emb, "emb"), _mat(gp, "gp"), _mat(gemb, "gemb")
+    batch = emb.shape[0]
+    npairs = nvec * (nvec - 1) // 2
+    rc = _timed("allpairs_bwd", lambda: (4 * batch * ((2 + int(accumulate)) * nvec * dim + npairs),
+                                         2 * batch * npairs * dim * 2),
+                _lib.load().ctr_allpairs_bwd, emb.data_ptr(), _ld(emb), batch, nvec, dim, gp.data_ptr(), _ld(gp),
+                gemb.data_ptr(), _ld(gemb), int(accumulate), _lib.stream_ptr())
+    _lib.check(rc, "ctr_allpairs_bwd")
+
+
+def _wide_args(x, user1, item1, w, b):
+    x = _mat(x, "x")
+    _lib.require_device(user1, item1, w, b)
+    return (x.data_ptr(), _ld(x), USER_COL, ITEM_COL, DENSE_COL0, w.shape[1], user1.data_ptr(), user1.shape[0],
+            item1.data_ptr(), item1.shape[0], w.data_ptr(), b.data_ptr())
+
+
+def fm_wide_fwd(emb, nvec, dim, x, user1, item1, wide_w, wide_b, out, err_flag=None) -> None:
+    emb, out = _mat(emb, "emb"), _mat(out, "out")
+    batch = emb.shape[0]
+    rc = _timed("fm_wide_fwd", lambda: (4 * batch * (nvec * dim + 45 + 3), 4 * batch * nvec * dim),
+                _lib.load().ctr_fm_wide_fwd, emb.data_ptr(), _ld(emb), batch, nvec, dim,
+                *_wide_args(x, user1, item1, wide_w, wide_b), out.data_ptr(), _ld(out), _lib.ptr(err_flag),
+                _lib.stream_ptr())
+    _lib.check(rc, "ctr_fm_wide_fwd")
+
+
+def fm_wide_bwd(emb, nvec, dim, x, user1, item1, wide_w, wide_b, gout, guser1, gitem1, gwide_w, gwide_b, gemb,
+                accumulate: bool) -> None:
+    emb, gout = _mat(emb, "emb"), _mat(gout, "gout")
+    batch = emb.shape[0]
+    rc = _timed("fm_wide_bwd", lambda: (4 * batch * ((2 + int(accumulate)) * nvec * dim + 45 + 5),
+                                        4 * batch * nvec * dim),
+                _lib.load().ctr_fm_wide_bwd, emb.data_ptr(), _ld(emb), batch, nvec, dim,
+                *_wide_args(x, user1, item1, wide_w, wide_b), gout.data_ptr(), _ld(gout), _lib.ptr(guser1),
+                _lib.ptr(gitem1), _lib.ptr(gwide_w), _lib.ptr(gwide_b), _lib.ptr(gemb),
+                _ld(gemb) if gemb is not None else 0, int(accumulate), _lib.stream_ptr())
+    _lib.check(rc, "ctr_fm_wide_bwd")
+
+
+def _pair_array(pairs):
+    flat = [v for p in pairs for v in p]
+    return (C.c_int32 * len(flat))(*flat)
+
+
+def ffm_head_fwd(emb, nvec, dim, pairs, x, user1, item1, lin_w, lin_b, prob, err_flag=None) -> None:
+    emb, prob = _mat(emb, "emb"), _mat(prob, "prob")
+    batch = emb.shape[0]
+    rc = _timed("ffm_head_fwd", lambda: (4 * batch * (nvec * dim + 45 + 3), 2 * batch * len(pairs) * dim),
+                _lib.load().ctr_ffm_head_fwd, emb.data_ptr(), _ld(emb), batch, nvec, dim, _pair_array(pairs),
+                len(pairs), *_wide_args(x, user1, item1, lin_w, lin_b), prob.data_ptr(), _ld(prob),
+                _lib.ptr(err_flag), _lib.stream_ptr())
+    _lib.check(rc, "ctr_ffm_head_fwd")
+
+
+def ffm_head_bwd(emb, nvec, dim, pairs, x, user1, item1, lin_w, lin_b, prob, gprob, guser1, gitem1, glin_w, glin_b,
+                 gemb) -> None:
+    emb, prob, gprob, gemb = _mat(emb, "emb"), _mat(prob, "prob"), _mat(gprob, "gprob"), _mat(gemb, "gemb")
+    batch = emb.shape[0]
+    rc = _timed("ffm_head_bwd", lambda: (4 * batch * (2 * nvec * dim + 45 + 6), 4 * batch * len(pairs) * dim),
+                _lib.load().ctr_ffm_head_bwd, emb.data_ptr(), _ld(emb), batch, nvec, dim, _pair_array(pairs),
+                len(pairs), *_wide_args(x, user1, item1, lin_w, lin_b), prob.data_ptr(), _ld(prob),
+                gprob.data_ptr(), _ld(gprob), _lib.ptr(guser1), _lib.ptr(gitem1), _lib.ptr(glin_w),
+                _lib.ptr(glin_b), gemb.data_ptr(), _ld(gemb), _lib.stream_ptr())
+    _lib.check(rc, "ctr_ffm_head_bwd")
+
+
+def act_bwd(y, gy, act: int, out, accumulate: bool) -> None:
+    y, gy, out = _mat(y, "y"), _mat(gy, "gy"), _mat(out, "out")
+    m, n = y.shape
+    rc = _timed(f"act_bwd[{m}x{n}]", lambda: (4 * m * n * (3 + int(accumulate)), m * n),
+                _lib.load().ctr_act_bwd, y.data_ptr(), _ld(y), gy.data_ptr(), _ld(gy), out.data_ptr(), _ld(out),
+                m, n, act, int(accumulate), _lib.stream_ptr())
+    _lib.check(rc, "ctr_act_bwd")

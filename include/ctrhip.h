@@ -124,6 +124,62 @@ int ctr_linear_bwd(const float* x, int64_t ldx, const float* w, int64_t ldw,
                    float* gw, int64_t ldgw, float* gb,
                    int64_t m, int n, int k, int act, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Feature interactions on the stacked embedding matrix emb (batch, >= nvec*dim)
+ * written by ctr_embed_fwd: vector f of sample b is emb[b*lde + f*dim ...].
+ * ---------------------------------------------------------------------- */
+
+/* PNN inner products (model/pnn.py:59-66): out[b, idx(i,j)] = <v_i, v_j>, i<j in
+ * lexicographic order, nvec*(nvec-1)/2 columns. */
+int ctr_allpairs_fwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim,
+                     float* out, int64_t ldo, void* stream);
+/* gemb[b,i,:] (= or +=) sum_{j!=i} gp[b, idx(i,j)] * v_j */
+int ctr_allpairs_bwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim,
+                     const float* gp, int64_t ldgp, float* gemb, int64_t ldg, int accumulate, void* stream);
+
+/* DeepFM wide part + FM second order (model/deepfm.py:63,71-77):
+ *   out[b*ldo] = user1[u] + item1[i] + (x[b, dense_col0..+ndense) . wide_w + wide_b)
+ *               + 0.5 * sum_e[(sum_f v_fe)^2 - sum_f v_fe^2]
+ * with u = (int64)x[b,user_col], i = (int64)x[b,item_col]; user1/item1 are the
+ * (vocab,1) tables `self.user` / `self.item`, wide_w the (1,ndense) weight. */
+int ctr_fm_wide_fwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim,
+                    const float* x, int64_t ldx, int user_col, int item_col, int dense_col0, int ndense,
+                    const float* user1, int64_t num_users, const float* item1, int64_t num_items,
+                    const float* wide_w, const float* wide_b, float* out, int64_t ldo,
+                    int32_t* err_flag, void* stream);
+/* g = gout[b*ldgo]: guser1[u] += g, gitem1[i] += g, gwide_w += sum_b g x, gwide_b += sum_b g,
+ * gemb[b,f,e] (= or +=) g * (sum_f' v_f'e - v_fe).  Any grad pointer may be NULL. */
+int ctr_fm_wide_bwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim,
+                    const float* x, int64_t ldx, int user_col, int item_col, int dense_col0, int ndense,
+                    const float* user1, int64_t num_users, const float* item1, int64_t num_items,
+                    const float* wide_w, const float* wide_b, const float* gout, int64_t ldgo,
+                    float* guser1, float* gitem1, float* gwide_w, float* gwide_b,
+                    float* gemb, int64_t ldg, int accumulate, void* stream);
+
+/* FFM head (model/ffm.py:62-86): cross = sum_p <v_a(p), v_b(p)> over the host pair
+ * list `pairs` (2*npairs ints, npairs <= 64), summed left to right;
+ *   prob[b*ldo] = sigmoid(user1[u] + item1[i] + sum_c (x[b,c] + cross) * lin_w[c] + lin_b)
+ * -- the reference adds the cross scalar to every dense input before its linear
+ * layer (ffm.py:84-86) and so does this. */
+int ctr_ffm_head_fwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim,
+                     const int32_t* pairs, int npairs,
+                     const float* x, int64_t ldx, int user_col, int item_col, int dense_col0, int ndense,
+                     const float* user1, int64_t num_users, const float* item1, int64_t num_items,
+                     const float* lin_w, const float* lin_b, float* prob, int64_t ldo,
+                     int32_t* err_flag, void* stream);
+int ctr_ffm_head_bwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim,
+                     const int32_t* pairs, int npairs,
+                     const float* x, int64_t ldx, int user_col, int item_col, int dense_col0, int ndense,
+                     const float* user1, int64_t num_users, const float* item1, int64_t num_items,
+                     const float* lin_w, const float* lin_b,
+                     const float* prob, int64_t ldp, const float* gprob, int64_t ldgp,
+                     float* guser1, float* gitem1, float* glin_w, float* glin_b,
+                     float* gemb, int64_t ldg, void* stream);
+
+/* out (= or +=) gy * act'(y): the residual branch of model/deepcrossing.py:26 */
+int ctr_act_bwd(const float* y, int64_t ldy, const float* gy, int64_t ldgy, float* out, int64_t ldo,
+                int64_t m, int n, int act, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

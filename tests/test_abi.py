@@ -81,3 +81,52 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(base, f)).read()
                 assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def _parse_header_prototypes():
+    """{name: (ret, [arg ctypes])} derived from the declarations in include/ctrhip.h"""
+    text = open(os.path.join(ROOT, "include", "ctrhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"(const\s+char\s*\*|int)\s+(ctr_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
+        kinds = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "ctr_field_t" in a:
+                    kinds.append("field*")
+                elif "int32_t*" in a.replace(" *", "*") and "const" in a:
+                    kinds.append("i32*")
+                elif "*" in a:
+                    kinds.append("ptr")
+                elif a.startswith("int64_t"):
+                    kinds.append("i64")
+                elif a.startswith("int ") or a.startswith("int32_t "):
+                    kinds.append("int")
+                else:
+                    raise AssertionError(f"unparsed parameter {a!r} of {name}")
+        protos[name] = ("str" if "char" in ret else "int", kinds)
+    return protos
+
+
+def test_ctypes_signatures_match_header_prototypes(lib):
+    protos = _parse_header_prototypes()
+    assert set(protos) == set(lib.SIGNATURES)
+    to_kind = {ctypes.c_void_p: "ptr", ctypes.c_int64: "i64", ctypes.c_int: "int", ctypes.c_char_p: "str"}
+    for name, (ret, kinds) in protos.items():
+        res, args = lib.SIGNATURES[name]
+        assert to_kind[res] == ret, name
+        got = []
+        for a in args:
+            if a in to_kind:
+                got.append(to_kind[a])
+            elif a is ctypes.POINTER(lib.Field):
+                got.append("field*")
+            elif a is ctypes.POINTER(ctypes.c_int32):
+                got.append("i32*")
+            else:
+                raise AssertionError(f"{name}: unexpected ctypes arg {a}")
+        # a device `int32_t* err_flag` is passed as a raw pointer; only host int arrays are typed
+        norm = ["ptr" if k == "i32*" and g == "ptr" else k for k, g in zip(kinds, got)]
+        assert got == norm, f"{name}: header {kinds} vs ctypes {got}"
