@@ -57,6 +57,12 @@ SIGNATURES = {
     "ctr_ffm_head_bwd": (_i, [_p, _l, _l, _i, _i, C.POINTER(C.c_int32), _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l,
                               _p, _p, _p, _l, _p, _l, _p, _p, _p, _p, _p, _l, _p]),
     "ctr_act_bwd": (_i, [_p, _l, _p, _l, _p, _l, _l, _i, _i, _i, _p]),
+    "ctr_din_concat_fwd": (_i, [_p, _l, _i, _p, _p, _l, _i, _p, _l, _p, _l, _p, _p]),
+    "ctr_din_pool_fwd": (_i, [_p, _p, _l, _l, _i, _i, _p, _p, _l, _i, _p]),
+    "ctr_din_pool_bwd": (_i, [_p, _p, _l, _l, _i, _i, _p, _l, _i, _p, _p]),
+    "ctr_din_concat_bwd": (_i, [_p, _p, _l, _l, _i, _i, _p, _l, _p, _p, _l, _i, _p, _l, _p, _p]),
+    "ctr_gru_fwd": (_i, [_p, _l, _p, _p, _l, _i, _i, _p, _p, _l, _p]),
+    "ctr_gru_bwd": (_i, [_p, _l, _p, _p, _p, _l, _i, _i, _p, _l, _p, _p, _p]),
 }
 
 _lock = threading.Lock()

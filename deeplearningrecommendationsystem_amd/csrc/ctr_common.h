@@ -75,3 +75,11 @@ __device__ __forceinline__ void ctr_stg(float4* p, float4 v) {
 __device__ __forceinline__ void ctr_atomic_add_global(float* p, float v) {
   (void)__builtin_amdgcn_global_atomic_fadd_f32((CTR_GLOBAL float*)p, v);
 }
+
+// internal (not part of the C ABI): single-output-unit linear layer, linear_n1.hip
+bool ctr_n1_supported(int k);
+int ctr_n1_fwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* res, int64_t ldr, float* y,
+               int64_t ldy, int64_t m, int k, int act, hipStream_t st);
+int ctr_n1_bwd(const float* x, int64_t ldx, const float* w, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
+               float* gx, int64_t ldgx, int accumulate_gx, float* gw, float* gb, int64_t m, int k, int act,
+               hipStream_t st);

@@ -1,0 +1,389 @@
+// DIN / DIEN attention over the behaviour sequence (model/din.py:33-53,
+// model/dien.py:23-39), the pieces around the attention MLP (which runs on the
+// MFMA linear kernels):
+//   concat_fwd : K3 sequence gather fused with the [h, h-t, t] operand build
+//   pool_fwd   : softmax over L (no padding mask, as the reference) + weighted sum
+//                (DIN) or per-position scaling (DIEN)
+//   pool_bwd   : gradient of the scores through the softmax
+//   concat_bwd : all gradient paths into the item table, scattered with fp32
+//                atomics; the pad row (id 0) that every padded history hits is
+//                pre-reduced per workgroup in LDS
+// Lane mapping everywhere: LPR lanes share one (b,l) row (dwordx4 each when
+// E % 4 == 0), a wave covers 64/LPR consecutive positions, coalesced in memory.
+#include "ctr_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline int pow2_ceil(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+struct SeqGeom {
+  int64_t batch;
+  int len;   // L
+  int dim;   // E
+  int vec;   // 4 or 1
+  int lpr;   // lanes per row (power of two <= 64)
+};
+
+inline SeqGeom make_geom(int64_t batch, int len, int dim, bool aligned) {
+  SeqGeom g;
+  g.batch = batch;
+  g.len = len;
+  g.dim = dim;
+  g.vec = (aligned && dim % 4 == 0) ? 4 : 1;
+  const int units = dim / g.vec;
+  g.lpr = pow2_ceil(units);
+  if (g.lpr > 64) g.lpr = 64;
+  return g;
+}
+
+template <int VEC>
+struct Pack;
+template <>
+struct Pack<1> {
+  float v[1];
+  __device__ __forceinline__ void load(const float* p) { v[0] = *p; }
+  __device__ __forceinline__ void store(float* p) const { *p = v[0]; }
+};
+template <>
+struct Pack<4> {
+  float v[4];
+  __device__ __forceinline__ void load(const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+
+__device__ __forceinline__ int64_t safe_row(int64_t r, int64_t vocab, int32_t* err) {
+  if (r < 0 || r >= vocab) {
+    if (err) *err = 1;
+    return 0;
+  }
+  return r;
+}
+
+// c[(b*L+l), 0:E] = h, [E:2E] = h - t, [2E:3E] = t ; tvec[b, 0:E] = t
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+concat_fwd_kernel(const SeqGeom g, const float* __restrict__ table, int64_t vocab, const int64_t* __restrict__ hist,
+                  const int64_t* __restrict__ target, float* __restrict__ c, int64_t ldc, float* __restrict__ tvec,
+                  int64_t ldt, int32_t* err) {
+  const int sub = threadIdx.x % g.lpr;
+  const int64_t rows = g.batch * g.len;
+  const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / g.lpr;
+  for (int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / g.lpr; row < rows; row += groups) {
+    const int64_t b = row / g.len;
+    const int l = (int)(row - b * g.len);
+    const int64_t hr = safe_row(hist[row], vocab, err);
+    const int64_t tr = safe_row(target[b], vocab, err);
+    for (int e = sub * VEC; e < g.dim; e += g.lpr * VEC) {
+      Pack<VEC> h, t, d;
+      h.load(table + hr * g.dim + e);
+      t.load(table + tr * g.dim + e);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) d.v[v] = h.v[v] - t.v[v];
+      float* dst = c + row * ldc + e;
+      h.store(dst);
+      d.store(dst + g.dim);
+      t.store(dst + 2 * g.dim);
+      if (l == 0 && tvec) t.store(tvec + b * ldt + e);
+    }
+  }
+}
+
+// one wave per sample.  a = softmax_L(score); summed: out[b,:] = sum_l a_l h_l, else
+// out[(b,l),:] = a_l h_l.  h_l is read from hsrc[(b*L+l)*ldh ...] (the first E columns
+// of the concat operand).
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+pool_fwd_kernel(const SeqGeom g, const float* __restrict__ score, const float* __restrict__ hsrc, int64_t ldh,
+                float* __restrict__ attn, float* __restrict__ out, int64_t ldo, int summed) {
+  const int lane = threadIdx.x & 63;
+  const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int sub = lane % g.lpr, rsub = lane / g.lpr, rows_per_iter = 64 / g.lpr;
+  for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < g.batch; b += waves) {
+    const float* s = score + b * g.len;
+    float mx = -INFINITY;
+    for (int l = lane; l < g.len; l += 64) mx = fmaxf(mx, s[l]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float den = 0.0f;
+    for (int l = lane; l < g.len; l += 64) den += expf(s[l] - mx);
+    den = ctr_wave_sum(den);
+
+    float* ab = attn + b * g.len;
+    for (int l = lane; l < g.len; l += 64) ab[l] = expf(s[l] - mx) / den;
+    // weighted rows (a_l recomputed per row group: same expression, same value)
+    float acc[8][VEC];
+    const int chunks = (g.dim + g.lpr * VEC - 1) / (g.lpr * VEC);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[q][v] = 0.0f;
+    for (int l0 = 0; l0 < g.len; l0 += rows_per_iter) {
+      const int l = l0 + rsub;
+      if (l < g.len) {
+        const float al = expf(s[l] - mx) / den;
+        const float* hr = hsrc + (b * g.len + l) * ldh;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int e = (sub + q * g.lpr) * VEC;
+          if (q < chunks && e < g.dim) {
+            Pack<VEC> h;
+            h.load(hr + e);
+            if (summed) {
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) acc[q][v] = fmaf(al, h.v[v], acc[q][v]);
+            } else {
+              Pack<VEC> o;
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) o.v[v] = h.v[v] * al;
+              o.store(out + (b * g.len + l) * ldo + e);
+            }
+          }
+        }
+      }
+    }
+    if (summed) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int e = (sub + q * g.lpr) * VEC;
+        if (q < chunks) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            float t = acc[q][v];
+            for (int o = g.lpr; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+            acc[q][v] = t;
+          }
+          if (rsub == 0 && e < g.dim) {
+            Pack<VEC> o;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o.v[v] = acc[q][v];
+            o.store(out + b * ldo + e);
+          }
+        }
+      }
+    }
+  }
+}
+
+// gscore[b,l] = a_l (ga_l - sum_k a_k ga_k),  ga_l = <gsrc_l, h_l>, gsrc_l = gout[b,:]
+// (summed) or gout[(b,l),:].  Two sweeps over the sample's rows (the second one hits
+// L2): the first forms sum_k a_k ga_k, the second recomputes ga_l bit-identically and
+// writes the result, so nothing is staged between lanes.
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+pool_bwd_kernel(const SeqGeom g, const float* __restrict__ attn, const float* __restrict__ hsrc, int64_t ldh,
+                const float* __restrict__ gout, int64_t ldgo, int summed, float* __restrict__ gscore) {
+  const int lane = threadIdx.x & 63;
+  const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int sub = lane % g.lpr, rsub = lane / g.lpr, rows_per_iter = 64 / g.lpr;
+  for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < g.batch; b += waves) {
+    const float* ab = attn + b * g.len;
+    float* gs = gscore + b * g.len;
+    float dotsum = 0.0f;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int l0 = 0; l0 < g.len; l0 += rows_per_iter) {
+        const int l = l0 + rsub;
+        float ga = 0.0f;
+        if (l < g.len) {
+          const float* hr = hsrc + (b * g.len + l) * ldh;
+          const float* gr = summed ? gout + b * ldgo : gout + (b * g.len + l) * ldgo;
+          for (int e = sub * VEC; e < g.dim; e += g.lpr * VEC) {
+            Pack<VEC> h, q;
+            h.load(hr + e);
+            q.load(gr + e);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) ga = fmaf(q.v[v], h.v[v], ga);
+          }
+        }
+        for (int o = g.lpr >> 1; o > 0; o >>= 1) ga += __shfl_xor(ga, o, 64);
+        if (l < g.len && sub == 0) {
+          if (pass == 0)
+            dotsum = fmaf(ab[l], ga, dotsum);
+          else
+            gs[l] = ab[l] * (ga - dotsum);
+        }
+      }
+      if (pass == 0) dotsum = ctr_wave_sum(dotsum);
+    }
+  }
+}
+
+// Scatter every gradient path into the dense item-table gradient:
+//   hist row  (b,l): g1 + g2 + a_l * gsrc_l        (gc = [g1,g2,g3] per position)
+//   target row b   : sum_l (g3 - g2) + gt_extra[b]
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+concat_bwd_kernel(const SeqGeom g, const int64_t* __restrict__ hist, const int64_t* __restrict__ target,
+                  int64_t vocab, const float* __restrict__ gc, int64_t ldc, const float* __restrict__ attn,
+                  const float* __restrict__ gout, int64_t ldgo, int summed, const float* __restrict__ gt_extra,
+                  int64_t ldgt, float* __restrict__ gtable) {
+  extern __shared__ float s_pad[];  // E floats: gradient of row 0 accumulated by this workgroup
+  for (int i = threadIdx.x; i < g.dim; i += blockDim.x) s_pad[i] = 0.0f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int sub = lane % g.lpr, rsub = lane / g.lpr, rows_per_iter = 64 / g.lpr;
+  const int chunks = (g.dim + g.lpr * VEC - 1) / (g.lpr * VEC);
+  for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < g.batch; b += waves) {
+    float tacc[8][VEC];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) tacc[q][v] = 0.0f;
+    for (int l0 = 0; l0 < g.len; l0 += rows_per_iter) {
+      const int l = l0 + rsub;
+      if (l < g.len) {
+        const int64_t row = b * g.len + l;
+        int64_t hr = hist[row];
+        if (hr < 0 || hr >= vocab) hr = 0;
+        const float al = attn[row];
+        const float* gr = summed ? gout + b * ldgo : gout + row * ldgo;
+        const float* gcr = gc + row * ldc;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int e = (sub + q * g.lpr) * VEC;
+          if (q < chunks && e < g.dim) {
+            Pack<VEC> g1, g2, g3, go;
+            g1.load(gcr + e);
+            g2.load(gcr + g.dim + e);
+            g3.load(gcr + 2 * g.dim + e);
+            go.load(gr + e);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+              const float gh = (g1.v[v] + g2.v[v]) + al * go.v[v];
+              tacc[q][v] += g3.v[v] - g2.v[v];
+              if (hr == 0)
+                atomicAdd(s_pad + e + v, gh);
+              else
+                unsafeAtomicAdd(gtable + hr * g.dim + e + v, gh);
+            }
+          }
+        }
+      }
+    }
+    int64_t tr = target[b];
+    if (tr < 0 || tr >= vocab) tr = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = (sub + q * g.lpr) * VEC;
+      if (q < chunks) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          float t = tacc[q][v];
+          for (int o = g.lpr; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+          if (rsub == 0 && e < g.dim) {
+            if (gt_extra) t += gt_extra[b * ldgt + e + v];
+            unsafeAtomicAdd(gtable + tr * g.dim + e + v, t);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < g.dim; i += blockDim.x) {
+    const float v = s_pad[i];
+    if (v != 0.0f) unsafeAtomicAdd(gtable + i, v);
+  }
+}
+
+inline int wave_grid(int64_t batch) {
+  int64_t blocks = ctr_ceil_div(batch, kBlock / 64);
+  return (int)(blocks < 2048 ? (blocks < 1 ? 1 : blocks) : 2048);
+}
+
+inline int check_dim(const SeqGeom& g) {
+  // a lane owns at most 8 chunks of a row
+  return g.lpr * g.vec * 8 >= g.dim ? CTR_OK : CTR_ELIMIT;
+}
+
+}  // namespace
+
+extern "C" int ctr_din_concat_fwd(const float* table, int64_t vocab, int dim, const int64_t* hist,
+                                  const int64_t* target, int64_t batch, int len, float* c, int64_t ldc, float* tvec,
+                                  int64_t ldt, int32_t* err_flag, void* stream) {
+  CTR_REQUIRE(batch >= 0 && len >= 0, CTR_EINVAL);
+  if (batch == 0 || len == 0) return CTR_OK;
+  CTR_REQUIRE(table && hist && target && c && vocab > 0 && dim > 0 && ldc >= 3 * (int64_t)dim, CTR_EINVAL);
+  CTR_REQUIRE(!tvec || ldt >= dim, CTR_EINVAL);
+  const bool al = ctr_aligned16(table) && ctr_aligned16(c) && ldc % 4 == 0 && (!tvec || (ctr_aligned16(tvec) && ldt % 4 == 0));
+  const SeqGeom g = make_geom(batch, len, dim, al);
+  const int grid = ctr_stream_grid(batch * len * g.lpr, kBlock);
+  hipStream_t st = (hipStream_t)stream;
+  if (g.vec == 4)
+    hipLaunchKernelGGL(concat_fwd_kernel<4>, dim3(grid), dim3(kBlock), 0, st, g, table, vocab, hist, target, c, ldc,
+                       tvec, ldt, err_flag);
+  else
+    hipLaunchKernelGGL(concat_fwd_kernel<1>, dim3(grid), dim3(kBlock), 0, st, g, table, vocab, hist, target, c, ldc,
+                       tvec, ldt, err_flag);
+  return ctr_launch_status();
+}
+
+extern "C" int ctr_din_pool_fwd(const float* score, const float* hsrc, int64_t ldh, int64_t batch, int len, int dim,
+                                float* attn, float* out, int64_t ldo, int summed, void* stream) {
+  CTR_REQUIRE(batch >= 0 && len >= 0, CTR_EINVAL);
+  if (batch == 0 || len == 0) return CTR_OK;
+  CTR_REQUIRE(score && hsrc && attn && out && dim > 0 && ldh >= dim && ldo >= dim, CTR_EINVAL);
+  const bool al = ctr_aligned16(hsrc) && ldh % 4 == 0 && ctr_aligned16(out) && ldo % 4 == 0;
+  const SeqGeom g = make_geom(batch, len, dim, al);
+  int rc = check_dim(g);
+  if (rc != CTR_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (g.vec == 4)
+    hipLaunchKernelGGL(pool_fwd_kernel<4>, dim3(wave_grid(batch)), dim3(kBlock), 0, st, g, score, hsrc, ldh, attn, out,
+                       ldo, summed);
+  else
+    hipLaunchKernelGGL(pool_fwd_kernel<1>, dim3(wave_grid(batch)), dim3(kBlock), 0, st, g, score, hsrc, ldh, attn, out,
+                       ldo, summed);
+  return ctr_launch_status();
+}
+
+extern "C" int ctr_din_pool_bwd(const float* attn, const float* hsrc, int64_t ldh, int64_t batch, int len, int dim,
+                                const float* gout, int64_t ldgo, int summed, float* gscore, void* stream) {
+  CTR_REQUIRE(batch >= 0 && len >= 0, CTR_EINVAL);
+  if (batch == 0 || len == 0) return CTR_OK;
+  CTR_REQUIRE(attn && hsrc && gout && gscore && dim > 0 && ldh >= dim && ldgo >= dim, CTR_EINVAL);
+  const bool al = ctr_aligned16(hsrc) && ldh % 4 == 0 && ctr_aligned16(gout) && ldgo % 4 == 0;
+  const SeqGeom g = make_geom(batch, len, dim, al);
+  hipStream_t st = (hipStream_t)stream;
+  if (g.vec == 4)
+    hipLaunchKernelGGL(pool_bwd_kernel<4>, dim3(wave_grid(batch)), dim3(kBlock), 0, st, g, attn, hsrc, ldh, gout, ldgo,
+                       summed, gscore);
+  else
+    hipLaunchKernelGGL(pool_bwd_kernel<1>, dim3(wave_grid(batch)), dim3(kBlock), 0, st, g, attn, hsrc, ldh, gout, ldgo,
+                       summed, gscore);
+  return ctr_launch_status();
+}
+
+extern "C" int ctr_din_concat_bwd(const int64_t* hist, const int64_t* target, int64_t vocab, int64_t batch, int len,
+                                  int dim, const float* gc, int64_t ldc, const float* attn, const float* gout,
+                                  int64_t ldgo, int summed, const float* gt_extra, int64_t ldgt, float* gtable,
+                                  void* stream) {
+  CTR_REQUIRE(batch >= 0 && len >= 0, CTR_EINVAL);
+  if (batch == 0 || len == 0) return CTR_OK;
+  CTR_REQUIRE(hist && target && gc && attn && gout && gtable && vocab > 0 && dim > 0, CTR_EINVAL);
+  CTR_REQUIRE(ldc >= 3 * (int64_t)dim && ldgo >= dim && (!gt_extra || ldgt >= dim), CTR_EINVAL);
+  const bool al = ctr_aligned16(gc) && ldc % 4 == 0 && ctr_aligned16(gout) && ldgo % 4 == 0;
+  const SeqGeom g = make_geom(batch, len, dim, al);
+  int rc = check_dim(g);
+  if (rc != CTR_OK) return rc;
+  int grid = wave_grid(batch);
+  if (grid > 1024) grid = 1024;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t dyn = (size_t)dim * sizeof(float);
+  if (g.vec == 4)
+    hipLaunchKernelGGL(concat_bwd_kernel<4>, dim3(grid), dim3(kBlock), dyn, st, g, hist, target, vocab, gc, ldc, attn,
+                       gout, ldgo, summed, gt_extra, ldgt, gtable);
+  else
+    hipLaunchKernelGGL(concat_bwd_kernel<1>, dim3(grid), dim3(kBlock), dyn, st, g, hist, target, vocab, gc, ldc, attn,
+                       gout, ldgo, summed, gt_extra, ldgt, gtable);
+  return ctr_launch_status();
+}

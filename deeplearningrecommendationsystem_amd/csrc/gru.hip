@@ -1,0 +1,211 @@
+// DIEN interest evolution: single-layer batch_first GRU, h0 = 0 (model/dien.py:47,61).
+// The input projection gi = X W_ih^T + b_ih for ALL steps is one MFMA GEMM (linear
+// kernel); what is inherently sequential -- gh = W_hh h_{t-1} + b_hh, the gates and
+// the state update, L dependent steps -- runs here, batched across samples: a group
+// of G >= E lanes owns one sample (lane j = hidden unit j), W_hh sits in LDS with an
+// odd row stride (row reads for the forward dots and column reads for the backward
+// W_hh^T product are both conflict-free), the running state is exchanged through LDS.
+// PyTorch gate order (r, z, n):  r = s(gi_r+gh_r), z = s(gi_z+gh_z),
+// n = tanh(gi_n + r*gh_n), h' = (1-z)*n + z*h.
+// Backward writes dgi_t and dgh_t for every step; the weight/bias/input gradients are
+// then GEMMs over all (b,t) rows (dW_ih = dgi^T X, dW_hh = dgh^T H_prev, dX = dgi W_ih).
+#include "ctr_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline int pow2_ceil(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+struct GruGeom {
+  int64_t batch;
+  int len, dim, group;  // group = lanes per sample (power of two >= dim)
+};
+
+__device__ __forceinline__ void load_whh(float* s_w, const float* __restrict__ w_hh, int dim) {
+  const int stride = dim + 1;
+  for (int i = threadIdx.x; i < 3 * dim * dim; i += blockDim.x) {
+    const int r = i / dim, c = i - r * dim;
+    s_w[r * stride + c] = w_hh[i];
+  }
+}
+
+// hbuf: (batch, len+1, dim); hbuf[b,0,:] = 0, hbuf[b,t+1,:] = h_t
+__global__ void __launch_bounds__(kBlock)
+gru_fwd_kernel(const GruGeom g, const float* __restrict__ gi, int64_t ldgi, const float* __restrict__ w_hh,
+               const float* __restrict__ b_hh, float* __restrict__ hbuf, float* __restrict__ last, int64_t ldl) {
+  extern __shared__ float lds[];
+  const int stride = g.dim + 1;
+  float* s_w = lds;                                  // [3E][E+1]
+  float* s_h = s_w + 3 * g.dim * stride;             // [2][samples][E]
+  const int per_block = kBlock / g.group;
+  const int sample = threadIdx.x / g.group, j = threadIdx.x % g.group;
+  const bool unit = j < g.dim;
+  load_whh(s_w, w_hh, g.dim);
+  const float br = unit ? b_hh[j] : 0.f, bz = unit ? b_hh[g.dim + j] : 0.f, bn = unit ? b_hh[2 * g.dim + j] : 0.f;
+  for (int64_t b0 = (int64_t)blockIdx.x * per_block; b0 < g.batch; b0 += (int64_t)gridDim.x * per_block) {
+    const int64_t b = b0 + sample;
+    const bool live = unit && b < g.batch;
+    float h = 0.0f;
+    if (unit) s_h[sample * g.dim + j] = 0.0f;
+    if (live) hbuf[b * (g.len + 1) * g.dim + j] = 0.0f;
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < g.len; ++t) {
+      float hn = 0.0f;
+      if (live) {
+        const float* hv = s_h + (cur * per_block + sample) * g.dim;
+        float ar = br, az = bz, an = bn;
+        const float* wr = s_w + j * stride;
+        const float* wz = s_w + (g.dim + j) * stride;
+        const float* wn = s_w + (2 * g.dim + j) * stride;
+        for (int k = 0; k < g.dim; ++k) {
+          const float hk = hv[k];
+          ar = fmaf(wr[k], hk, ar);
+          az = fmaf(wz[k], hk, az);
+          an = fmaf(wn[k], hk, an);
+        }
+        const float* gir = gi + (b * g.len + t) * ldgi;
+        const float r = ctr_sigmoid(gir[j] + ar);
+        const float z = ctr_sigmoid(gir[g.dim + j] + az);
+        const float n = tanhf(gir[2 * g.dim + j] + r * an);
+        hn = (1.0f - z) * n + z * h;
+        hbuf[(b * (g.len + 1) + t + 1) * g.dim + j] = hn;
+      }
+      if (unit) s_h[((cur ^ 1) * per_block + sample) * g.dim + j] = hn;
+      h = hn;
+      cur ^= 1;
+      __syncthreads();
+    }
+    if (live && last) last[b * ldl + j] = h;
+    __syncthreads();
+  }
+}
+
+// dgi: (batch*len, 3E) row (b,t);  dgh: (batch, len+1, 3E) with row 0 zero and row t+1 = dgh_t
+__global__ void __launch_bounds__(kBlock)
+gru_bwd_kernel(const GruGeom g, const float* __restrict__ gi, int64_t ldgi, const float* __restrict__ w_hh,
+               const float* __restrict__ b_hh, const float* __restrict__ hbuf, const float* __restrict__ glast,
+               int64_t ldgl, float* __restrict__ dgi, float* __restrict__ dgh) {
+  extern __shared__ float lds[];
+  const int stride = g.dim + 1;
+  const int per_block = kBlock / g.group;
+  float* s_w = lds;                                   // [3E][E+1]
+  float* s_h = s_w + 3 * g.dim * stride;              // [samples][E]  h_{t-1}
+  float* s_d = s_h + per_block * g.dim;               // [samples][3E] dgh_t
+  const int sample = threadIdx.x / g.group, j = threadIdx.x % g.group;
+  const bool unit = j < g.dim;
+  load_whh(s_w, w_hh, g.dim);
+  const float br = unit ? b_hh[j] : 0.f, bz = unit ? b_hh[g.dim + j] : 0.f, bn = unit ? b_hh[2 * g.dim + j] : 0.f;
+  for (int64_t b0 = (int64_t)blockIdx.x * per_block; b0 < g.batch; b0 += (int64_t)gridDim.x * per_block) {
+    const int64_t b = b0 + sample;
+    const bool live = unit && b < g.batch;
+    float dh = live ? glast[b * ldgl + j] : 0.0f;
+    if (live) {
+      float* z0 = dgh + b * (g.len + 1) * 3 * g.dim;
+      z0[j] = 0.0f; z0[g.dim + j] = 0.0f; z0[2 * g.dim + j] = 0.0f;
+    }
+    for (int t = g.len - 1; t >= 0; --t) {
+      float hp = 0.0f;
+      if (live) hp = hbuf[(b * (g.len + 1) + t) * g.dim + j];
+      if (unit) s_h[sample * g.dim + j] = hp;
+      __syncthreads();
+      float dhp = 0.0f;
+      if (live) {
+        const float* hv = s_h + sample * g.dim;
+        float ar = br, az = bz, an = bn;
+        const float* wr = s_w + j * stride;
+        const float* wz = s_w + (g.dim + j) * stride;
+        const float* wn = s_w + (2 * g.dim + j) * stride;
+        for (int k = 0; k < g.dim; ++k) {
+          const float hk = hv[k];
+          ar = fmaf(wr[k], hk, ar);
+          az = fmaf(wz[k], hk, az);
+          an = fmaf(wn[k], hk, an);
+        }
+        const float* gir = gi + (b * g.len + t) * ldgi;
+        const float r = ctr_sigmoid(gir[j] + ar);
+        const float z = ctr_sigmoid(gir[g.dim + j] + az);
+        const float n = tanhf(gir[2 * g.dim + j] + r * an);
+        const float dz = dh * (hp - n);
+        const float dn = dh * (1.0f - z);
+        dhp = dh * z;
+        const float dan = dn * (1.0f - n * n);
+        const float dar = dan * an * r * (1.0f - r);
+        const float daz = dz * z * (1.0f - z);
+        float* o = dgi + (b * g.len + t) * 3 * g.dim;
+        o[j] = dar; o[g.dim + j] = daz; o[2 * g.dim + j] = dan;
+        float* q = dgh + (b * (g.len + 1) + t + 1) * 3 * g.dim;
+        const float dhn = dan * r;
+        q[j] = dar; q[g.dim + j] = daz; q[2 * g.dim + j] = dhn;
+        float* sd = s_d + sample * 3 * g.dim;
+        sd[j] = dar; sd[g.dim + j] = daz; sd[2 * g.dim + j] = dhn;
+      }
+      __syncthreads();
+      if (live) {
+        // dh_{t-1}[j] = dh_t[j]*z + sum_i W_hh[i][j] * dgh_t[i]
+        const float* sd = s_d + sample * 3 * g.dim;
+        float acc = dhp;
+        for (int i = 0; i < 3 * g.dim; ++i) acc = fmaf(s_w[i * stride + j], sd[i], acc);
+        dh = acc;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+inline size_t fwd_lds(const GruGeom& g) {
+  return sizeof(float) * (3 * g.dim * (g.dim + 1) + 2 * (kBlock / g.group) * g.dim);
+}
+inline size_t bwd_lds(const GruGeom& g) {
+  return sizeof(float) * (3 * g.dim * (g.dim + 1) + 4 * (kBlock / g.group) * g.dim);
+}
+
+inline int make_geom(int64_t batch, int len, int dim, GruGeom* g) {
+  CTR_REQUIRE(dim >= 1 && dim <= 64, CTR_ELIMIT);  // W_hh must fit LDS, one lane per hidden unit
+  g->batch = batch;
+  g->len = len;
+  g->dim = dim;
+  g->group = pow2_ceil(dim);
+  return CTR_OK;
+}
+
+inline int grid_for(const GruGeom& g) {
+  const int64_t blocks = ctr_ceil_div(g.batch, kBlock / g.group);
+  return (int)(blocks < 2048 ? blocks : 2048);
+}
+
+}  // namespace
+
+extern "C" int ctr_gru_fwd(const float* gi, int64_t ldgi, const float* w_hh, const float* b_hh, int64_t batch, int len,
+                           int dim, float* hbuf, float* last, int64_t ldl, void* stream) {
+  CTR_REQUIRE(batch >= 0 && len >= 0, CTR_EINVAL);
+  if (batch == 0) return CTR_OK;
+  CTR_REQUIRE(w_hh && b_hh && hbuf && (len == 0 || gi) && ldgi >= 3 * (int64_t)dim, CTR_EINVAL);
+  CTR_REQUIRE(!last || ldl >= dim, CTR_EINVAL);
+  GruGeom g;
+  int rc = make_geom(batch, len, dim, &g);
+  if (rc != CTR_OK) return rc;
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3(grid_for(g)), dim3(kBlock), fwd_lds(g), (hipStream_t)stream, g, gi, ldgi, w_hh,
+                     b_hh, hbuf, last, ldl);
+  return ctr_launch_status();
+}
+
+extern "C" int ctr_gru_bwd(const float* gi, int64_t ldgi, const float* w_hh, const float* b_hh, const float* hbuf,
+                           int64_t batch, int len, int dim, const float* glast, int64_t ldgl, float* dgi, float* dgh,
+                           void* stream) {
+  CTR_REQUIRE(batch >= 0 && len >= 0, CTR_EINVAL);
+  if (batch == 0) return CTR_OK;
+  CTR_REQUIRE(w_hh && b_hh && hbuf && glast && dgh && (len == 0 || (gi && dgi)), CTR_EINVAL);
+  CTR_REQUIRE(ldgi >= 3 * (int64_t)dim && ldgl >= dim, CTR_EINVAL);
+  GruGeom g;
+  int rc = make_geom(batch, len, dim, &g);
+  if (rc != CTR_OK) return rc;
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(grid_for(g)), dim3(kBlock), bwd_lds(g), (hipStream_t)stream, g, gi, ldgi, w_hh,
+                     b_hh, hbuf, glast, ldgl, dgi, dgh);
+  return ctr_launch_status();
+}

@@ -283,7 +283,8 @@ extern "C" int ctr_linear_fwd(const float* x, int64_t ldx, const float* w, int64
   CTR_REQUIRE(x && w && y, CTR_EINVAL);
   CTR_REQUIRE(ldx >= k && ldw >= k && ldy >= n && (!residual || ldr >= n), CTR_EINVAL);
   CTR_REQUIRE(act >= CTR_ACT_NONE && act <= CTR_ACT_SIGMOID, CTR_EINVAL);
-  if (m == 0) return CTR_OK;
+  if (n == 1 && ctr_n1_supported(k))
+    return ctr_n1_fwd(x, ldx, w, bias, residual, ldr, y, ldy, m, k, act, (hipStream_t)stream);
   FwdEpi e{y, ldy, bias, residual, ldr, act};
   return launch<KC, KC>(plain(x, ldx, m, k), plain(w, ldw, n, k), e, m, n, k, 1, nullptr, (hipStream_t)stream);
 }
@@ -301,6 +302,8 @@ extern "C" int ctr_linear_bwd(const float* x, int64_t ldx, const float* w, int64
   CTR_REQUIRE(!gw || ldgw >= k, CTR_EINVAL);
   if (m == 0) return CTR_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (n == 1 && ctr_n1_supported(k) && (gx || gw || gb))
+    return ctr_n1_bwd(x, ldx, w, y, ldy, gy, ldgy, gx, ldgx, accumulate_gx, gw, gb, m, k, act, st);
   GzSrc gz;
   gz.gy = plain(gy, ldgy, m, n);
   gz.y = plain(y ? y : gy, y ? ldy : ldgy, m, n);

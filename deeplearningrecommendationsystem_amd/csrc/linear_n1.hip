@@ -1,0 +1,184 @@
+// nn.Linear with ONE output unit (the sigmoid heads, DIN's attention score layer,
+// DeepFM's last deep layer): y[m] = act(x[m,:] . w + b (+ r[m])).  A 32-wide MFMA
+// tile would idle 31/32 of the matrix core and, worse, re-read nothing: this is a
+// streaming dot product, HBM-bound on x.  LPR lanes share a row (dwordx4 each when
+// the rows are 16-B aligned), a workgroup walks rows with a grid stride.
+// Backward in one pass over x: gx[m,:] = gz[m] w,  gw += sum_m gz[m] x[m,:],
+// gb += sum_m gz[m]; per-lane register partials, one LDS reduction per workgroup,
+// then k+1 global atomics per workgroup.
+#include "ctr_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxChunks = 8;  // k-chunks a lane may own: k <= 64 * 4 * 8
+
+struct N1Args {
+  const float* x; int64_t ldx;
+  const float* w;
+  const float* bias;
+  const float* res; int64_t ldr;
+  float* y; int64_t ldy;
+  int64_t m; int k; int act; int lpr;
+};
+
+template <int VEC>
+__global__ void __launch_bounds__(kBlock) n1_fwd_kernel(const N1Args a) {
+  const int sub = threadIdx.x % a.lpr;
+  const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / a.lpr;
+  const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / a.lpr;
+  for (int64_t r = gid; r < a.m; r += groups) {
+    const float* xr = a.x + r * a.ldx;
+    float acc = 0.0f;
+    for (int c = sub * VEC; c < a.k; c += a.lpr * VEC) {
+      if (VEC == 4) {
+        const float4 xv = *reinterpret_cast<const float4*>(xr + c);
+        const float4 wv = *reinterpret_cast<const float4*>(a.w + c);
+        acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+      } else {
+        acc = fmaf(xr[c], a.w[c], acc);
+      }
+    }
+    for (int o = a.lpr >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (sub == 0) {
+      float z = acc;
+      if (a.bias) z += a.bias[0];
+      if (a.res) z += a.res[r * a.ldr];
+      a.y[r * a.ldy] = ctr_act(z, a.act);
+    }
+  }
+}
+
+struct N1BwdArgs {
+  const float* x; int64_t ldx;
+  const float* w;
+  const float* y; int64_t ldy;
+  const float* gy; int64_t ldgy;
+  float* gx; int64_t ldgx; int accumulate_gx;
+  float* gw; float* gb;
+  int64_t m; int k; int act; int lpr;
+};
+
+template <int VEC>
+__global__ void __launch_bounds__(kBlock) n1_bwd_kernel(const N1BwdArgs a) {
+  __shared__ float s_red[kBlock * VEC];
+  const int sub = threadIdx.x % a.lpr;
+  const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / a.lpr;
+  const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / a.lpr;
+  float wacc[kMaxChunks][VEC];
+#pragma unroll
+  for (int q = 0; q < kMaxChunks; ++q)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) wacc[q][v] = 0.0f;
+  float bacc = 0.0f;
+  const bool need_w = a.gw != nullptr;
+  for (int64_t r = gid; r < a.m; r += groups) {
+    float gz = a.gy[r * a.ldgy];
+    if (a.act != CTR_ACT_NONE) gz *= ctr_act_grad(a.y[r * a.ldy], a.act);
+    if (sub == 0) bacc += gz;
+    const float* xr = a.x ? a.x + r * a.ldx : nullptr;
+    float* gxr = a.gx ? a.gx + r * a.ldgx : nullptr;
+#pragma unroll
+    for (int q = 0; q < kMaxChunks; ++q) {
+      const int c = (sub + q * a.lpr) * VEC;
+      if (c < a.k) {
+        if (VEC == 4) {
+          if (need_w) {
+            const float4 xv = *reinterpret_cast<const float4*>(xr + c);
+            wacc[q][0] = fmaf(gz, xv.x, wacc[q][0]); wacc[q][1] = fmaf(gz, xv.y, wacc[q][1]);
+            wacc[q][2] = fmaf(gz, xv.z, wacc[q][2]); wacc[q][3] = fmaf(gz, xv.w, wacc[q][3]);
+          }
+          if (gxr) {
+            const float4 wv = *reinterpret_cast<const float4*>(a.w + c);
+            float4 o = make_float4(gz * wv.x, gz * wv.y, gz * wv.z, gz * wv.w);
+            if (a.accumulate_gx) {
+              const float4 p = *reinterpret_cast<const float4*>(gxr + c);
+              o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+            }
+            *reinterpret_cast<float4*>(gxr + c) = o;
+          }
+        } else {
+          if (need_w) wacc[q][0] = fmaf(gz, xr[c], wacc[q][0]);
+          if (gxr) gxr[c] = a.accumulate_gx ? gxr[c] + gz * a.w[c] : gz * a.w[c];
+        }
+      }
+    }
+  }
+  // reduce the per-group partials of the workgroup, chunk by chunk
+  const int ngroups = kBlock / a.lpr;
+  if (need_w) {
+#pragma unroll
+    for (int q = 0; q < kMaxChunks; ++q) {
+      if (q * a.lpr * VEC >= a.k) break;
+      __syncthreads();
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) s_red[threadIdx.x * VEC + v] = wacc[q][v];
+      __syncthreads();
+      if (threadIdx.x < a.lpr) {
+        const int c = (threadIdx.x + q * a.lpr) * VEC;
+        if (c < a.k) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            float t = 0.0f;
+            for (int g = 0; g < ngroups; ++g) t += s_red[(g * a.lpr + threadIdx.x) * VEC + v];
+            if (t != 0.0f) unsafeAtomicAdd(a.gw + c + v, t);
+          }
+        }
+      }
+    }
+  }
+  if (a.gb) {
+    __syncthreads();
+    s_red[threadIdx.x] = bacc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.0f;
+      for (int g = 0; g < kBlock; ++g) t += s_red[g];
+      if (t != 0.0f) unsafeAtomicAdd(a.gb, t);
+    }
+  }
+}
+
+inline int pow2_ceil(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+}  // namespace
+
+bool ctr_n1_supported(int k) { return k <= 64 * kMaxChunks; }
+
+int ctr_n1_fwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* res, int64_t ldr, float* y,
+               int64_t ldy, int64_t m, int k, int act, hipStream_t st) {
+  const bool vec = k % 4 == 0 && ldx % 4 == 0 && ctr_aligned16(x) && ctr_aligned16(w);
+  const int units = vec ? k / 4 : k;
+  int lpr = pow2_ceil(units);
+  if (lpr > 64) lpr = 64;
+  N1Args a{x, ldx, w, bias, res, ldr, y, ldy, m, k, act, lpr};
+  const int grid = ctr_stream_grid(m * lpr, kBlock);
+  if (vec)
+    hipLaunchKernelGGL(n1_fwd_kernel<4>, dim3(grid), dim3(kBlock), 0, st, a);
+  else
+    hipLaunchKernelGGL(n1_fwd_kernel<1>, dim3(grid), dim3(kBlock), 0, st, a);
+  return ctr_launch_status();
+}
+
+int ctr_n1_bwd(const float* x, int64_t ldx, const float* w, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
+               float* gx, int64_t ldgx, int accumulate_gx, float* gw, float* gb, int64_t m, int k, int act,
+               hipStream_t st) {
+  const bool vec = k % 4 == 0 && (!x || (ldx % 4 == 0 && ctr_aligned16(x))) && (!w || ctr_aligned16(w)) &&
+                   (!gx || (ldgx % 4 == 0 && ctr_aligned16(gx)));
+  const int units = vec ? k / 4 : k;
+  int lpr = pow2_ceil(units);
+  if (lpr > 64) lpr = 64;
+  if ((vec ? 4 : 1) * lpr * kMaxChunks < k) return CTR_ELIMIT;
+  N1BwdArgs a{x, ldx, w, y, ldy, gy, ldgy, gx, ldgx, accumulate_gx, gw, gb, m, k, act, lpr};
+  int grid = ctr_stream_grid(m * lpr, kBlock);
+  if (grid > 1024) grid = 1024;  // k+1 atomics per workgroup at the end
+  if (vec)
+    hipLaunchKernelGGL(n1_bwd_kernel<4>, dim3(grid), dim3(kBlock), 0, st, a);
+  else
+    hipLaunchKernelGGL(n1_bwd_kernel<1>, dim3(grid), dim3(kBlock), 0, st, a);
+  return ctr_launch_status();
+}

@@ -7,5 +7,7 @@ from .deepfm import DeepFM
 from .pnn import PNN
 from .ffm import FFM
 from .deepcrossing import DeepCrossing
+from .din import DIN
+from .dien import DIEN
 
-__all__ = ["MatrixFactorization", "NeuralCF", "DeepFM", "PNN", "FFM", "DeepCrossing"]
+__all__ = ["MatrixFactorization", "NeuralCF", "DeepFM", "PNN", "FFM", "DeepCrossing", "DIN", "DIEN"]

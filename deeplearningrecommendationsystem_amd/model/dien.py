@@ -1,0 +1,107 @@
+"""DIEN -- counterpart of the reference's model/dien.py:8-81."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+from torch.nn.init import xavier_normal_
+
+from .. import ops
+from ..ops import ACT_NONE, Layer
+from .din import SequenceModel, attention_layers, fc_layers
+
+
+class DIN(nn.Module):
+    """parameter container of DIEN's attention unit (reference model/dien.py:8-39:
+    attention MLP 3E -> 64 -> 32 -> 1, returns the un-summed weighted history)"""
+
+    def __init__(self, num_items, embed_size):
+        super().__init__()
+        self.item_embedding = nn.Embedding(num_items, embed_size)
+        self.attention = nn.Sequential(nn.Linear(embed_size * 3, 64), nn.ReLU(), nn.Linear(64, 32), nn.ReLU(),
+                                       nn.Linear(32, 1))
+        xavier_normal_(self.item_embedding.weight.data)
+
+
+class DIEN(SequenceModel):
+    """``DIEN(num_items, embed_size)``; ``forward(hist, target_item) -> (B,1)``.
+
+    attention (as DIN, un-summed) -> gi = seq W_ih^T + b_ih as ONE GEMM over all
+    B*L rows -> sequential GRU kernel (h0 = 0) -> hidden[-1] lands in the left half
+    of the fc input next to t -> fc MLP + sigmoid."""
+
+    def __init__(self, num_items, embed_size):
+        super().__init__()
+        self.din = DIN(num_items, embed_size)
+        self.interest_evolution = nn.GRU(embed_size, embed_size, batch_first=True)
+        self.fc = nn.Sequential(nn.Linear(embed_size * 2, 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU(),
+                                nn.Linear(64, 1), nn.Sigmoid())
+
+    def _params(self):
+        p = [self.din.item_embedding.weight]
+        for k in (0, 2, 4):
+            p += [self.din.attention[k].weight, self.din.attention[k].bias]
+        for k in (0, 2, 4):
+            p += [self.fc[k].weight, self.fc[k].bias]
+        g = self.interest_evolution
+        p += [g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0]
+        return p
+
+    def forward(self, hist, target_item):
+        return self._run_sequence(hist, target_item, self._params())
+
+    def run_forward(self, inputs, params):
+        hist, target = inputs
+        table = params[0]
+        att, fc = attention_layers(params[1:7]), fc_layers(params[7:13])
+        w_ih, w_hh, b_ih, b_hh = params[13:17]
+        batch, length = hist.shape
+        dim = table.shape[1]
+        dev = table.device
+        c = torch.empty((batch * length, 3 * dim), dtype=torch.float32, device=dev)
+        fcin = torch.empty((batch, 2 * dim), dtype=torch.float32, device=dev)
+        ops.din_concat_fwd(table, hist, target, c, fcin[:, dim:], self._flag)
+        att_acts = ops.mlp_fwd(c, att)
+        attn = torch.empty((batch, length), dtype=torch.float32, device=dev)
+        seq = torch.empty((batch * length, dim), dtype=torch.float32, device=dev)
+        ops.din_pool_fwd(att_acts[-1], c, batch, length, dim, attn, seq, summed=False)
+        gi = ops.linear_fwd(seq, w_ih, b_ih)
+        hbuf = torch.empty((batch * (length + 1), dim), dtype=torch.float32, device=dev)
+        ops.gru_fwd(gi, w_hh, b_hh, batch, length, dim, hbuf, fcin[:, :dim])
+        fc_acts = ops.mlp_fwd(fcin, fc)
+        return fc_acts[-1], (att_acts, attn, seq, gi, hbuf, fc_acts)
+
+    def run_backward(self, state, inputs, params, gprob):
+        hist, target = inputs
+        att_acts, attn, seq, gi, hbuf, fc_acts = state
+        table = params[0]
+        att, fc = attention_layers(params[1:7]), fc_layers(params[7:13])
+        w_ih, w_hh, b_ih, b_hh = params[13:17]
+        batch, length = hist.shape
+        dim = table.shape[1]
+        dev = table.device
+        c = att_acts[0]
+        fc_grads, gfcin = ops.mlp_bwd(fc_acts, fc, gprob, None)
+        dgi = torch.empty((batch * length, 3 * dim), dtype=torch.float32, device=dev)
+        dgh = torch.empty((batch * (length + 1), 3 * dim), dtype=torch.float32, device=dev)
+        ops.gru_bwd(gi, w_hh, b_hh, hbuf, batch, length, dim, gfcin[:, :dim], dgi, dgh)
+        g_w_ih, g_w_hh, g_b_ih, g_b_hh = (torch.zeros_like(t) for t in (w_ih, w_hh, b_ih, b_hh))
+        gseq = torch.empty_like(seq)
+        ops.linear_bwd(seq, w_ih, None, dgi, ACT_NONE, gseq, g_w_ih, g_b_ih)
+        # dW_hh = sum_{b,t} dgh_t (x) h_{t-1}: rows r+1 of dgh against rows r of hbuf; the
+        # zero row at the head of every sample makes the pairs that straddle samples vanish
+        rows = batch * (length + 1) - 1
+        if rows > 0:
+            ops.linear_bwd(hbuf[:rows], w_hh, None, dgh[1:], ACT_NONE, None, g_w_hh, g_b_hh)
+        gscore = torch.empty((batch * length, 1), dtype=torch.float32, device=dev)
+        ops.din_pool_bwd(attn, c, batch, length, dim, gseq, False, gscore)
+        att_grads, gc = ops.mlp_bwd(att_acts, att, gscore, None)
+        gtable = torch.zeros_like(table)
+        ops.din_concat_bwd(hist, target, table.shape[0], dim, gc, attn, gseq, False, gfcin[:, dim:], gtable)
+        grads = [gtable]
+        for gw, gb in att_grads + fc_grads:
+            grads += [gw, gb]
+        grads += [g_w_ih, g_w_hh, g_b_ih, g_b_hh]
+        return grads
+
+    def recommendation(self, num_users, num_items, hist_list, k):
+        return self._rank_histories(num_users, num_items, hist_list, k)

@@ -1,0 +1,112 @@
+"""DIN -- counterpart of the reference's model/din.py:9-66."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.init import xavier_normal_
+
+from .. import ops
+from ..ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, Layer
+from ._base import CtrModule, _ModelFunction
+
+
+def attention_layers(p):
+    """(w0,b0,w2,b2,w4,b4) -> Linear+ReLU, Linear+ReLU, Linear"""
+    return [Layer(p[0], p[1], ACT_RELU), Layer(p[2], p[3], ACT_RELU), Layer(p[4], p[5], ACT_NONE)]
+
+
+def fc_layers(p):
+    return [Layer(p[0], p[1], ACT_RELU), Layer(p[2], p[3], ACT_RELU), Layer(p[4], p[5], ACT_SIGMOID)]
+
+
+class SequenceModel(CtrModule):
+    """shared plumbing of the (hist, target) models"""
+
+    def _run_sequence(self, hist, target, params):
+        self._need_device(hist, target, params[0])
+        if hist.dim() != 2 or target.dim() != 1 or hist.shape[0] != target.shape[0]:
+            raise ValueError(f"expected hist (B,L) and target (B,), got {tuple(hist.shape)} {tuple(target.shape)}")
+        object.__setattr__(self, "_flag", self._err_flag(hist.device))
+        out = _ModelFunction.apply(self, 2, hist.contiguous(), target.contiguous(), *params)
+        self._raise_if_bad_index()
+        return out
+
+    def _rank_histories(self, num_users, num_items, hist_list, k):
+        """reference recommendation(): the user's whole history against every
+        item (model/din.py:55-66)"""
+        rows = []
+        dev = next(self.parameters()).device
+        targets = torch.arange(0, num_items, device=dev)
+        with torch.no_grad():
+            for u in range(num_users):
+                hist = torch.tensor(hist_list[u]).repeat(num_items, 1).to(dev)
+                scores = self.forward(hist, targets)
+                rows.append(torch.topk(scores, k, dim=0).indices.view(1, -1).tolist()[0])
+        return np.array(rows)
+
+
+class DIN(SequenceModel):
+    """``DIN(num_items, embed_size)``; ``forward(hist (B,L) int64, target_item (B,) int64) -> (B,1)``.
+
+    Pipeline: gather + [h, h-t, t] operand (one kernel) -> attention MLP on the
+    matrix cores over all B*L positions -> softmax over L + weighted sum written
+    straight into the left half of the fc input, whose right half (t) the gather
+    kernel already filled -> fc MLP + sigmoid."""
+
+    def __init__(self, num_items, embed_size):
+        super().__init__()
+        self.item_embedding = nn.Embedding(num_items, embed_size)
+        self.attention = nn.Sequential(nn.Linear(embed_size * 3, 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU(),
+                                       nn.Linear(64, 1))
+        self.fc = nn.Sequential(nn.Linear(embed_size * 2, 256), nn.ReLU(), nn.Linear(256, 128), nn.ReLU(),
+                                nn.Linear(128, 1), nn.Sigmoid())
+        xavier_normal_(self.item_embedding.weight.data)
+
+    def _params(self):
+        p = [self.item_embedding.weight]
+        for seq in (self.attention, self.fc):
+            for k in (0, 2, 4):
+                p += [seq[k].weight, seq[k].bias]
+        return p
+
+    def forward(self, hist, target_item):
+        return self._run_sequence(hist, target_item, self._params())
+
+    def run_forward(self, inputs, params):
+        hist, target = inputs
+        table = params[0]
+        att, fc = attention_layers(params[1:7]), fc_layers(params[7:13])
+        batch, length = hist.shape
+        dim = table.shape[1]
+        dev = table.device
+        c = torch.empty((batch * length, 3 * dim), dtype=torch.float32, device=dev)
+        fcin = torch.empty((batch, 2 * dim), dtype=torch.float32, device=dev)
+        ops.din_concat_fwd(table, hist, target, c, fcin[:, dim:], self._flag)
+        att_acts = ops.mlp_fwd(c, att)
+        attn = torch.empty((batch, length), dtype=torch.float32, device=dev)
+        ops.din_pool_fwd(att_acts[-1], c, batch, length, dim, attn, fcin[:, :dim], summed=True)
+        fc_acts = ops.mlp_fwd(fcin, fc)
+        return fc_acts[-1], (att_acts, attn, fc_acts)
+
+    def run_backward(self, state, inputs, params, gprob):
+        hist, target = inputs
+        att_acts, attn, fc_acts = state
+        table = params[0]
+        att, fc = attention_layers(params[1:7]), fc_layers(params[7:13])
+        batch, length = hist.shape
+        dim = table.shape[1]
+        c, fcin = att_acts[0], fc_acts[0]
+        fc_grads, gfcin = ops.mlp_bwd(fc_acts, fc, gprob, None)
+        gscore = torch.empty((batch * length, 1), dtype=torch.float32, device=table.device)
+        ops.din_pool_bwd(attn, c, batch, length, dim, gfcin[:, :dim], True, gscore)
+        att_grads, gc = ops.mlp_bwd(att_acts, att, gscore, None)
+        gtable = torch.zeros_like(table)
+        ops.din_concat_bwd(hist, target, table.shape[0], dim, gc, attn, gfcin[:, :dim], True, gfcin[:, dim:], gtable)
+        grads = [gtable]
+        for gw, gb in att_grads + fc_grads:
+            grads += [gw, gb]
+        return grads
+
+    def recommendation(self, num_users, num_items, hist_list, k):
+        return self._rank_histories(num_users, num_items, hist_list, k)

@@ -391,3 +391,61 @@ def act_bwd(y, gy, act: int, out, accumulate: bool) -> None:
                 _lib.load().ctr_act_bwd, y.data_ptr(), _ld(y), gy.data_ptr(), _ld(gy), out.data_ptr(), _ld(out),
                 m, n, act, int(accumulate), _lib.stream_ptr())
     _lib.check(rc, "ctr_act_bwd")
+
+
+# ---------------------------------------------------------------------------
+# DIN / DIEN sequence attention and GRU
+# ---------------------------------------------------------------------------
+def din_concat_fwd(table, hist, target, c, tvec, err_flag=None) -> None:
+    _lib.require_device(table, hist, target)
+    c = _mat(c, "c")
+    batch, length = hist.shape
+    dim = table.shape[1]
+    rc = _timed("din_concat_fwd", lambda: (batch * length * (dim * 4 + 8 + 12 * dim) + batch * (8 + 8 * dim), 0),
+                _lib.load().ctr_din_concat_fwd, table.data_ptr(), table.shape[0], dim, hist.data_ptr(),
+                target.data_ptr(), batch, length, c.data_ptr(), _ld(c), _lib.ptr(tvec),
+                _ld(tvec) if tvec is not None else 0, _lib.ptr(err_flag), _lib.stream_ptr())
+    _lib.check(rc, "ctr_din_concat_fwd")
+
+
+def din_pool_fwd(score, hsrc, batch, length, dim, attn, out, summed: bool) -> None:
+    hsrc, out = _mat(hsrc, "hsrc"), _mat(out, "out")
+    rc = _timed("din_pool_fwd", lambda: (4 * batch * length * (2 + dim * (1 if summed else 2)), 2 * batch * length * dim),
+                _lib.load().ctr_din_pool_fwd, score.data_ptr(), hsrc.data_ptr(), _ld(hsrc), batch, length, dim,
+                attn.data_ptr(), out.data_ptr(), _ld(out), int(summed), _lib.stream_ptr())
+    _lib.check(rc, "ctr_din_pool_fwd")
+
+
+def din_pool_bwd(attn, hsrc, batch, length, dim, gout, summed: bool, gscore) -> None:
+    hsrc, gout = _mat(hsrc, "hsrc"), _mat(gout, "gout")
+    rc = _timed("din_pool_bwd", lambda: (4 * batch * length * (2 + dim * (1 if summed else 2)), 2 * batch * length * dim),
+                _lib.load().ctr_din_pool_bwd, attn.data_ptr(), hsrc.data_ptr(), _ld(hsrc), batch, length, dim,
+                gout.data_ptr(), _ld(gout), int(summed), gscore.data_ptr(), _lib.stream_ptr())
+    _lib.check(rc, "ctr_din_pool_bwd")
+
+
+def din_concat_bwd(hist, target, vocab, dim, gc, attn, gout, summed: bool, gt_extra, gtable) -> None:
+    gc, gout = _mat(gc, "gc"), _mat(gout, "gout")
+    batch, length = hist.shape
+    rc = _timed("din_concat_bwd", lambda: (batch * length * (8 + 4 + 12 * dim + 8 * dim) + batch * 16 * dim, 0),
+                _lib.load().ctr_din_concat_bwd, hist.data_ptr(), target.data_ptr(), vocab, batch, length, dim,
+                gc.data_ptr(), _ld(gc), attn.data_ptr(), gout.data_ptr(), _ld(gout), int(summed),
+                _lib.ptr(gt_extra), _ld(gt_extra) if gt_extra is not None else 0, gtable.data_ptr(),
+                _lib.stream_ptr())
+    _lib.check(rc, "ctr_din_concat_bwd")
+
+
+def gru_fwd(gi, w_hh, b_hh, batch, length, dim, hbuf, last) -> None:
+    gi = _mat(gi, "gi")
+    rc = _timed("gru_fwd", lambda: (4 * batch * length * 4 * dim, 6 * batch * length * dim * dim),
+                _lib.load().ctr_gru_fwd, gi.data_ptr(), _ld(gi), w_hh.data_ptr(), b_hh.data_ptr(), batch, length, dim,
+                hbuf.data_ptr(), _lib.ptr(last), _ld(last) if last is not None else 0, _lib.stream_ptr())
+    _lib.check(rc, "ctr_gru_fwd")
+
+
+def gru_bwd(gi, w_hh, b_hh, hbuf, batch, length, dim, glast, dgi, dgh) -> None:
+    gi, glast = _mat(gi, "gi"), _mat(glast, "glast")
+    rc = _timed("gru_bwd", lambda: (4 * batch * length * 10 * dim, 12 * batch * length * dim * dim),
+                _lib.load().ctr_gru_bwd, gi.data_ptr(), _ld(gi), w_hh.data_ptr(), b_hh.data_ptr(), hbuf.data_ptr(),
+                batch, length, dim, glast.data_ptr(), _ld(glast), dgi.data_ptr(), dgh.data_ptr(), _lib.stream_ptr())
+    _lib.check(rc, "ctr_gru_bwd")

@@ -180,6 +180,49 @@ int ctr_ffm_head_bwd(const float* emb, int64_t lde, int64_t batch, int nvec, int
 int ctr_act_bwd(const float* y, int64_t ldy, const float* gy, int64_t ldgy, float* out, int64_t ldo,
                 int64_t m, int n, int act, int accumulate, void* stream);
 
+/* ------------------------------------------------------------------------
+ * DIN / DIEN attention over the behaviour sequence (model/din.py:33-53,
+ * model/dien.py:23-39).  hist is (batch, len) int64 row-major, target (batch,).
+ * ---------------------------------------------------------------------- */
+
+/* K3 sequence gather fused with the attention operand (din.py:35-42):
+ *   c[(b*len+l)*ldc + 0:E] = h, [E:2E] = h - t, [2E:3E] = t,  h = table[hist[b,l]],
+ *   t = table[target[b]];  tvec[b*ldt + 0:E] = t  (tvec may be NULL). */
+int ctr_din_concat_fwd(const float* table, int64_t vocab, int dim, const int64_t* hist, const int64_t* target,
+                       int64_t batch, int len, float* c, int64_t ldc, float* tvec, int64_t ldt,
+                       int32_t* err_flag, void* stream);
+/* attn[b,:] = softmax_len(score[b,:]) with no padding mask (din.py:44); h_l is read
+ * from hsrc[(b*len+l)*ldh ...].  summed != 0: out[b*ldo ...] = sum_l attn_l h_l
+ * (din.py:47); summed == 0: out[(b*len+l)*ldo ...] = attn_l h_l (dien.py:37). */
+int ctr_din_pool_fwd(const float* score, const float* hsrc, int64_t ldh, int64_t batch, int len, int dim,
+                     float* attn, float* out, int64_t ldo, int summed, void* stream);
+/* gradient of the scores through pooling + softmax; gout as `out` above */
+int ctr_din_pool_bwd(const float* attn, const float* hsrc, int64_t ldh, int64_t batch, int len, int dim,
+                     const float* gout, int64_t ldgo, int summed, float* gscore, void* stream);
+/* every gradient path into the dense item-table gradient (+=, fp32 atomics):
+ *   row hist[b,l]  += gc[.,0:E] + gc[.,E:2E] + attn[b,l] * gout_l
+ *   row target[b]  += sum_l (gc[.,2E:3E] - gc[.,E:2E]) + gt_extra[b]   (gt_extra may be NULL) */
+int ctr_din_concat_bwd(const int64_t* hist, const int64_t* target, int64_t vocab, int64_t batch, int len, int dim,
+                       const float* gc, int64_t ldc, const float* attn, const float* gout, int64_t ldgo,
+                       int summed, const float* gt_extra, int64_t ldgt, float* gtable, void* stream);
+
+/* ------------------------------------------------------------------------
+ * DIEN interest evolution: nn.GRU(E, E, batch_first=True), one layer, h0 = 0
+ * (model/dien.py:47,61), dim <= 64.  gi = X W_ih^T + b_ih for all steps is a
+ * ctr_linear_fwd call; these run the recurrence.
+ *   hbuf: (batch, len+1, dim), hbuf[b,0,:] = 0, hbuf[b,t+1,:] = h_t; `last`
+ *   (nullable) receives hidden[-1] = h_{len-1} at last[b*ldl ...].
+ * Backward writes dgi (batch*len, 3*dim) and dgh (batch, len+1, 3*dim; row 0 zero,
+ * row t+1 = gradient of W_hh h_{t-1} + b_hh), from which
+ *   dW_ih = dgi^T X, db_ih = sum dgi, dX = dgi W_ih,
+ *   dW_hh = dgh[1:]^T hbuf[:-1], db_hh = sum dgh       are ctr_linear_bwd calls.
+ * ---------------------------------------------------------------------- */
+int ctr_gru_fwd(const float* gi, int64_t ldgi, const float* w_hh, const float* b_hh, int64_t batch, int len,
+                int dim, float* hbuf, float* last, int64_t ldl, void* stream);
+int ctr_gru_bwd(const float* gi, int64_t ldgi, const float* w_hh, const float* b_hh, const float* hbuf,
+                int64_t batch, int len, int dim, const float* glast, int64_t ldgl, float* dgi, float* dgh,
+                void* stream);
+
 #ifdef __cplusplus
 }
 #endif
