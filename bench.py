@@ -35,48 +35,88 @@ F32_MFMA_PEAK_TF = 157.3    # dense fp32 matrix peak
 BATCH = 65536
 
 
-def build_workload(name: str, device, rank: int):
+WORKLOADS = {
+    # name: (oracle key, description)   -- shapes from BASELINE.json configs / SURVEY.md 8(d)
+    "neuralcf": "neuralcf mf_dim=64 layers=[128,64,32,16,8] users=943 items=1682 batch=65536/gpu (BASELINE configs[1])",
+    "mf": "mf emb=64 users=943 items=1682 batch=65536/gpu",
+    "deepfm": "deepfm users=items=1e6 emb=16 hidden=[512,256,128,1] batch=65536/gpu (BASELINE configs[2])",
+    "pnn": "pnn inner emb=16 hidden=[256,128,64,32] ml-100k vocab batch=65536/gpu (BASELINE configs[2])",
+    "ffm": "ffm k=32 ml-100k vocab batch=65536/gpu",
+    "deepcrossing": "deepcrossing emb=32 hidden=[256,128,64,32] ml-100k vocab batch=65536/gpu",
+    "din": "din items=1e7 emb=64 L=100 batch=32768/gpu (BASELINE configs[4], single GPU)",
+    "dien": "dien items=1e7 emb=16 L=100 batch=32768/gpu (BASELINE configs[4], single GPU)",
+}
+
+
+def make_inputs(name: str, rank: int, batch: int):
     from deeplearningrecommendationsystem_amd import synth
-    from deeplearningrecommendationsystem_amd import model as zoo
     gen = synth.generator(1234 + rank)
+    if name in ("neuralcf", "mf"):
+        u, i = synth.id_batch(batch, gen=gen)
+        return [u, i], synth.labels(batch, name != "mf", gen)
+    if name in ("deepfm",):
+        return [synth.feature_batch(batch, 1_000_000, 1_000_000, gen)], synth.labels(batch, True, gen)
+    if name in ("pnn", "ffm", "deepcrossing"):
+        return [synth.feature_batch(batch, gen=gen)], synth.labels(batch, True, gen)
+    if name in ("din", "dien"):
+        hist, target = synth.hist_batch(batch, 100, 10_000_000, gen)
+        return [hist, target], synth.labels(batch, True, gen)
+    raise SystemExit(f"unknown workload {name}")
+
+
+def make_model(name: str):
+    from deeplearningrecommendationsystem_amd import model as zoo
     torch.manual_seed(1234)  # identical replicas on every rank
     if name == "neuralcf":
-        # BASELINE.json configs[1]: model/neuralcf.py, emb_dim 64, batch 65536, ml-100k ids
-        m = zoo.NeuralCF(943, 1682, 64, [128, 64, 32, 16, 8])
-        u, i = synth.id_batch(BATCH, gen=gen)
-        inputs, y = [u, i], synth.labels(BATCH, True, gen)
-        desc = "neuralcf mf_dim=64 layers=[128,64,32,16,8] users=943 items=1682 batch=65536/gpu (BASELINE configs[1])"
-    elif name == "mf":
-        m = zoo.MatrixFactorization(943, 1682, 64)
-        u, i = synth.id_batch(BATCH, gen=gen)
-        inputs, y = [u, i], synth.labels(BATCH, False, gen)
-        desc = "mf emb=64 users=943 items=1682 batch=65536/gpu"
-    else:
-        raise SystemExit(f"unknown workload {name}")
-    return m.to(device), [t.to(device) for t in inputs], y.to(device), desc
+        return zoo.NeuralCF(943, 1682, 64, [128, 64, 32, 16, 8])
+    if name == "mf":
+        return zoo.MatrixFactorization(943, 1682, 64)
+    if name == "deepfm":
+        return zoo.DeepFM(1_000_000, 1_000_000, [512, 256, 128, 1], 16)
+    if name == "pnn":
+        return zoo.PNN(16, [256, 128, 64, 32])
+    if name == "ffm":
+        return zoo.FFM(43, 32)
+    if name == "deepcrossing":
+        return zoo.DeepCrossing(943, 1682, 32, [256, 128, 64, 32])
+    if name == "din":
+        return zoo.DIN(10_000_000, 64)
+    if name == "dien":
+        return zoo.DIEN(10_000_000, 16)
+    raise SystemExit(f"unknown workload {name}")
+
+
+def batch_of(name: str) -> int:
+    return 32768 if name in ("din", "dien") else BATCH
+
+
+def build_workload(name: str, device, rank: int):
+    if name not in WORKLOADS:
+        raise SystemExit(f"unknown workload {name}; choose from {sorted(WORKLOADS)}")
+    m = make_model(name)
+    inputs, y = make_inputs(name, rank, batch_of(name))
+    return m.to(device), [t.to(device) for t in inputs], y.to(device), WORKLOADS[name]
 
 
 def cpu_baseline(name: str, model, budget_s: float = 15.0):
     """time the CPU oracle on the same workload (bounded sample), rank 0 only"""
-    from deeplearningrecommendationsystem_amd import synth
     from oracle import ctr_oracle as orc  # checker/baseline only, never on the product path
     threads = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU
     torch.set_num_threads(threads)
+    batch = batch_of(name)
     params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    gen = synth.generator(1234)
-    u, i = synth.id_batch(BATCH, gen=gen)
-    y = synth.labels(BATCH, name != "mf", gen)
-    orc.step(name, params, [u, i], y)  # warm-up
+    inputs, y = make_inputs(name, 0, batch)
+    orc.step(name, params, inputs, y)  # warm-up
     t0 = time.perf_counter()
-    orc.step(name, params, [u, i], y)
+    orc.step(name, params, inputs, y)
     one = time.perf_counter() - t0
-    reps = max(3, min(200, int(budget_s / max(one, 1e-4))))
+    reps = max(2, min(200, int(budget_s / max(one, 1e-4))))
     t0 = time.perf_counter()
     for _ in range(reps):
-        orc.step(name, params, [u, i], y)
+        orc.step(name, params, inputs, y)
     dt = (time.perf_counter() - t0) / reps
-    return {"value": BATCH / dt, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} fwd+bwd steps of batch {BATCH} through oracle/ctr_oracle.py (torch CPU, fp32)",
+    return {"value": batch / dt, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} fwd+bwd steps of batch {batch} through oracle/ctr_oracle.py (torch CPU, fp32)",
             "ms_per_step": dt * 1e3}
 
 
@@ -101,6 +141,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="neuralcf")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,7 +165,7 @@ def main():
     bucket = GradBucket(model.parameters()) if world > 1 else None
     model.train()
 
-    def step():
+    def eager_step():
         model.zero_grad(set_to_none=True)
         prob = model(*inputs)
         loss = loss_fn(prob, y)
@@ -132,6 +173,18 @@ def main():
         if bucket is not None:
             bucket.all_reduce_mean()
         return loss
+
+    step = eager_step
+    if not args.no_graph:
+        # the same fwd + loss + bwd launches, captured once and replayed as one hipGraph
+        from deeplearningrecommendationsystem_amd.graph import GraphedStep
+        graphed = GraphedStep(model, loss_fn, inputs, y)
+
+        def step():
+            loss = graphed()
+            if bucket is not None:
+                bucket.all_reduce_mean()
+            return loss
 
     def barrier():
         if world > 1:
@@ -151,13 +204,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * BATCH * args.steps / elapsed
+    value = world * batch_of(args.workload) * args.steps / elapsed
 
     # per-kernel durations: the same steps again with a HIP event pair around every launch
     prof = ops.KernelProfiler()
     ops.set_profiler(prof)
     for _ in range(args.steps):
-        step()
+        eager_step()
     ops.set_profiler(None)
     kernels = prof.summary()
     if world > 1:
@@ -168,13 +221,14 @@ def main():
         dominant = max(kernels, key=lambda k: kernels[k]["total_us"])
         kernel_us = sum(v["total_us"] for v in kernels.values()) / args.steps
         out = {
-            "metric": "CTR samples/sec fwd+bwd at batch 65536",
+            "metric": "CTR samples/sec fwd+bwd at batch 65536" if batch_of(args.workload) == BATCH else
+                      f"CTR samples/sec fwd+bwd at batch {batch_of(args.workload)}",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "global_batch": world * BATCH,
+            "config": {"workload": desc, "global_batch": world * batch_of(args.workload),
                        "parallelism": f"dp{world}" if world > 1 else "single"},
-            "loss": float(loss.item()),
+            "loss": float(loss.item()), "launch": "eager" if args.no_graph else "hipGraph replay",
             "roofline": entries[dominant],
             "gather_roofline": entries.get("embed_fwd"),
             "kernels": {k: {"avg_us": round(v["avg_us"], 2), "calls_per_step": v["calls"] / args.steps,
@@ -182,7 +236,7 @@ def main():
                         for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["total_us"])},
             "gpu_kernel_us_per_step": round(kernel_us, 1),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload in ("neuralcf", "mf", "pnn", "ffm", "deepcrossing"):
             out["cpu_baseline"] = cpu_baseline(args.workload, model)
         print(json.dumps(out))
     if world > 1:

@@ -14,8 +14,8 @@ import threading
 import torch  # noqa: F401  (maps libamdhip64 first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libctrhip.so")
-ABI_VERSION = 1
+LIB_PATH = os.environ.get("CTRHIP_LIB", os.path.join(_HERE, "libctrhip.so"))  # env override: A/B builds
+ABI_VERSION = 2
 
 CTR_MAX_FIELDS = 32
 FIELD_ID_I64, FIELD_ID_F32, FIELD_BAG, FIELD_DENSE, FIELD_PROD_I64 = range(5)
@@ -42,20 +42,20 @@ SIGNATURES = {
     "ctr_strerror": (C.c_char_p, [_i]),
     "ctr_target_arch": (C.c_char_p, []),
     "ctr_embed_fwd": (_i, [C.POINTER(Field), _i, _p, _l, _l, _p, _l, _p, _p]),
-    "ctr_embed_bwd": (_i, [C.POINTER(Field), _i, _p, _l, _l, _p, _l, _p]),
+    "ctr_embed_bwd": (_i, [C.POINTER(Field), _i, _p, _l, _l, _p, _l, _p, _l, _p]),
     "ctr_mf_fwd": (_i, [_p, _l, _p, _l, _i, _p, _p, _l, _p, _p, _p]),
     "ctr_mf_bwd": (_i, [_p, _l, _p, _l, _i, _p, _p, _l, _p, _p, _p, _p, _p]),
     "ctr_linear_fwd": (_i, [_p, _l, _p, _l, _p, _p, _l, _p, _l, _l, _i, _i, _i, _p]),
-    "ctr_linear_bwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _p, _l, _i, _p, _l, _p, _l, _i, _i, _i, _p]),
+    "ctr_linear_bwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _p, _l, _i, _p, _l, _p, _l, _i, _i, _i, _p, _l, _p]),
     "ctr_allpairs_fwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _p]),
     "ctr_allpairs_bwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _p, _l, _i, _p]),
     "ctr_fm_wide_fwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _p, _l, _p, _p]),
     "ctr_fm_wide_bwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _p, _l,
-                             _p, _p, _p, _p, _p, _l, _i, _p]),
+                             _p, _p, _p, _p, _p, _l, _i, _p, _l, _p]),
     "ctr_ffm_head_fwd": (_i, [_p, _l, _l, _i, _i, C.POINTER(C.c_int32), _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l,
                               _p, _p, _p, _l, _p, _p]),
     "ctr_ffm_head_bwd": (_i, [_p, _l, _l, _i, _i, C.POINTER(C.c_int32), _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l,
-                              _p, _p, _p, _l, _p, _l, _p, _p, _p, _p, _p, _l, _p]),
+                              _p, _p, _p, _l, _p, _l, _p, _p, _p, _p, _p, _l, _p, _l, _p]),
     "ctr_act_bwd": (_i, [_p, _l, _p, _l, _p, _l, _l, _i, _i, _i, _p]),
     "ctr_din_concat_fwd": (_i, [_p, _l, _i, _p, _p, _l, _i, _p, _l, _p, _l, _p, _p]),
     "ctr_din_pool_fwd": (_i, [_p, _p, _l, _l, _i, _i, _p, _p, _l, _i, _p]),

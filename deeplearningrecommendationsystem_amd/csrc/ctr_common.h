@@ -76,10 +76,44 @@ __device__ __forceinline__ void ctr_atomic_add_global(float* p, float v) {
   (void)__builtin_amdgcn_global_atomic_fadd_f32((CTR_GLOBAL float*)p, v);
 }
 
+// Unsigned division by a run-time constant without the ~40-instruction u64/u32
+// software divide (Hacker's Delight 10-9 / libdivide "branchfree" form), exact for
+// every 32-bit numerator:  q = (t + ((n - t) >> s1)) >> s2,  t = mulhi(m, n).
+struct CtrFastDiv {
+  uint32_t d, m, s1, s2;
+};
+static inline CtrFastDiv ctr_fastdiv(uint32_t d) {
+  CtrFastDiv f;
+  f.d = d;
+  uint32_t s = 0;
+  while ((1ull << s) < d) ++s;
+  f.m = (uint32_t)(((1ull << 32) * ((1ull << s) - d)) / d + 1);
+  f.s1 = s < 1 ? s : 1;
+  f.s2 = s > 0 ? s - 1 : 0;
+  return f;
+}
+__device__ __forceinline__ uint32_t ctr_div(uint32_t n, const CtrFastDiv& f) {
+  const uint32_t t = __umulhi(f.m, n);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
+// internal: second pass over per-workgroup partials (reduce.hip)
+#define CTR_MAX_SEGMENTS 40
+struct CtrSegment {
+  int64_t off;    // first float of the segment inside one partial
+  int64_t count;  // floats
+  float* dst;     // accumulated into (+=)
+};
+struct CtrSegments {
+  int n;
+  CtrSegment s[CTR_MAX_SEGMENTS];
+};
+int ctr_reduce_segments(const float* ws, int parts, int64_t stride, const CtrSegments& segs, hipStream_t st);
+
 // internal (not part of the C ABI): single-output-unit linear layer, linear_n1.hip
 bool ctr_n1_supported(int k);
 int ctr_n1_fwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* res, int64_t ldr, float* y,
                int64_t ldy, int64_t m, int k, int act, hipStream_t st);
 int ctr_n1_bwd(const float* x, int64_t ldx, const float* w, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
                float* gx, int64_t ldgx, int accumulate_gx, float* gw, float* gb, int64_t m, int k, int act,
-               hipStream_t st);
+               float* ws, int64_t ws_floats, hipStream_t st);

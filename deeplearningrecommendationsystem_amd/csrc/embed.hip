@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int kMaxUnits = 2048;   // units per sample the per-block LUT can hold
+constexpr int kMaxUnits = 4096;   // units per sample the per-block LUT can hold
 constexpr int kBlock = 256;
 
 struct FieldPack {
@@ -94,16 +94,16 @@ __device__ __forceinline__ int64_t checked_row(int64_t r, int64_t vocab, int32_t
 template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 embed_fwd_kernel(const FieldPack P, int nfields, const float* __restrict__ x, int64_t ldx, uint32_t batch,
-                 float* __restrict__ out, int64_t ldo, int32_t* err_flag) {
+                 float* __restrict__ out, int64_t ldo, int32_t* err_flag, const CtrFastDiv div) {
   using V = typename Vec<VEC>::T;
   __shared__ UnitLut s;
   build_lut<VEC>(s, P, nfields);
-  const uint32_t upr = (uint32_t)s.start[nfields];
-  const uint64_t total = (uint64_t)batch * upr;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-    const uint32_t b = (uint32_t)(g / upr);
-    const uint32_t u = (uint32_t)(g - (uint64_t)b * upr);
+  const uint32_t upr = div.d;          // units per sample; batch * upr < 2^32 (checked on the host)
+  const uint32_t total = batch * upr;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    const uint32_t b = ctr_div(g, div);
+    const uint32_t u = g - b * upr;
     const int fi = s.field_of[u];
     const ctr_field_t& f = s.f[fi];
     const int off = (int)(u - (uint32_t)s.start[fi]) * VEC;
@@ -147,7 +147,8 @@ embed_fwd_kernel(const FieldPack P, int nfields, const float* __restrict__ x, in
 template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 embed_bwd_kernel(const FieldPack P, int nfields, const float* __restrict__ x, int64_t ldx, uint32_t batch,
-                 const float* __restrict__ gout, int64_t ldo, int bag_floats) {
+                 const float* __restrict__ gout, int64_t ldo, int bag_floats, const CtrFastDiv div,
+                 float* __restrict__ ws /* [gridDim.x][bag_floats] partials, or NULL -> atomics */) {
   using V = typename Vec<VEC>::T;
   __shared__ UnitLut s;
   __shared__ int s_bag_off[CTR_MAX_FIELDS];
@@ -163,12 +164,12 @@ embed_bwd_kernel(const FieldPack P, int nfields, const float* __restrict__ x, in
   for (int i = threadIdx.x; i < bag_floats; i += blockDim.x) s_bag[i] = 0.0f;
   __syncthreads();
 
-  const uint32_t upr = (uint32_t)s.start[nfields];
-  const uint64_t total = (uint64_t)batch * upr;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
-    const uint32_t b = (uint32_t)(g / upr);
-    const uint32_t u = (uint32_t)(g - (uint64_t)b * upr);
+  const uint32_t upr = div.d;
+  const uint32_t total = batch * upr;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    const uint32_t b = ctr_div(g, div);
+    const uint32_t u = g - b * upr;
     const int fi = s.field_of[u];
     const ctr_field_t& f = s.f[fi];
     if (f.kind == CTR_FIELD_DENSE) continue;
@@ -210,6 +211,11 @@ embed_bwd_kernel(const FieldPack P, int nfields, const float* __restrict__ x, in
     }
   }
   __syncthreads();
+  if (ws) {
+    // plain stores of this workgroup's partial; reduce.hip adds the partials up
+    for (int i = threadIdx.x; i < bag_floats; i += blockDim.x) ws[(int64_t)blockIdx.x * bag_floats + i] = s_bag[i];
+    return;
+  }
   for (int fi = 0; fi < nfields; ++fi) {
     const ctr_field_t& f = s.f[fi];
     if (f.kind != CTR_FIELD_BAG || !f.grad) continue;
@@ -220,6 +226,95 @@ embed_bwd_kernel(const FieldPack P, int nfields, const float* __restrict__ x, in
       if (v != 0.0f) ctr_atomic_add_global(f.grad + i, v);
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+struct TablePtrs {
+  const float* p[CTR_MAX_FIELDS];
+  int64_t vocab[CTR_MAX_FIELDS];
+};
+
+template <int UNROLL>
+__global__ void __launch_bounds__(kBlock)
+embed_ids_fast_kernel(const TablePtrs T, int nfields, int lpr, int width, const int64_t* __restrict__ idx,
+                      uint32_t items, float* __restrict__ out, int64_t ldo, int32_t* err_flag, const CtrFastDiv div) {
+  __shared__ const float* s_tab[CTR_MAX_FIELDS];
+  __shared__ int64_t s_vocab[CTR_MAX_FIELDS];
+  if (threadIdx.x < nfields) {
+    s_tab[threadIdx.x] = T.p[threadIdx.x];
+    s_vocab[threadIdx.x] = T.vocab[threadIdx.x];
+  }
+  __syncthreads();
+  const int sub = threadIdx.x % lpr;                       // which dwordx4 of the row
+  const uint32_t per_block = (kBlock / lpr) * UNROLL;      // items per workgroup pass
+  const uint32_t slot = threadIdx.x / lpr;
+  for (uint32_t base = blockIdx.x * per_block; base < items; base += gridDim.x * per_block) {
+    const float* src[UNROLL];
+    float* dst[UNROLL];
+    bool live[UNROLL];
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k) {
+      const uint32_t i = base + slot + k * (kBlock / lpr);
+      live[k] = i < items;
+      const uint32_t ii = live[k] ? i : 0;
+      const uint32_t b = ctr_div(ii, div);
+      const uint32_t f = ii - b * div.d;
+      int64_t r = ctr_ldg(idx + ii);
+      if (r < 0 || r >= s_vocab[f]) {
+        if (err_flag) *err_flag = 1;
+        r = 0;
+      }
+      src[k] = s_tab[f] + r * width + sub * 4;
+      dst[k] = out + (int64_t)b * ldo + f * width + sub * 4;
+    }
+    ctr_f32x4 v[UNROLL];
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k) {
+#ifdef CTR_NT_LOADS
+      v[k] = __builtin_nontemporal_load((const CTR_GLOBAL ctr_f32x4*)(src[k]));
+#else
+      v[k] = *(const CTR_GLOBAL ctr_f32x4*)(src[k]);
+#endif
+    }
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k)
+      if (live[k]) {
+#ifdef CTR_NT_STORES
+        __builtin_nontemporal_store(v[k], (CTR_GLOBAL ctr_f32x4*)(dst[k]));
+#else
+        *(CTR_GLOBAL ctr_f32x4*)(dst[k]) = v[k];
+#endif
+      }
+  }
+}
+
+// returns true (and launches) when the descriptor list matches the fast-path shape
+bool try_fast_ids(const ctr_field_t* f, int n, int64_t batch, float* out, int64_t ldo, int32_t* err_flag,
+                  hipStream_t st, int* rc) {
+  const int w = f[0].width;
+  if (w % 4 != 0 || w > 256) return false;
+  const int lpr = w / 4;
+  if ((lpr & (lpr - 1)) != 0 || lpr > 64) return false;
+  if (!ctr_aligned16(out) || ldo % 4 != 0 || batch * n >= (1ll << 32)) return false;
+  TablePtrs T;
+  for (int i = 0; i < n; ++i) {
+    if (f[i].kind != CTR_FIELD_ID_I64 || f[i].width != w || f[i].out_col != i * w) return false;
+    if (f[i].idx != f[0].idx + i || f[i].idx_stride != n || !ctr_aligned16(f[i].table)) return false;
+    T.p[i] = f[i].table;
+    T.vocab[i] = f[i].vocab;
+  }
+#ifndef CTR_FAST_UNROLL
+#define CTR_FAST_UNROLL 4
+#endif
+  constexpr int kUnroll = CTR_FAST_UNROLL;
+  const uint32_t items = (uint32_t)(batch * n);
+  const uint32_t per_block = (kBlock / lpr) * kUnroll;
+  int64_t grid = ctr_ceil_div(items, per_block);
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(embed_ids_fast_kernel<kUnroll>, dim3((unsigned)grid), dim3(kBlock), 0, st, T, n, lpr, w, f[0].idx,
+                     items, out, ldo, err_flag, ctr_fastdiv((uint32_t)n));
+  *rc = ctr_launch_status();
+  return true;
 }
 
 struct Plan {
@@ -269,7 +364,10 @@ int make_plan(const ctr_field_t* fields, int nfields, const float* x, int64_t ld
     plan->pack.f[i] = f;
   }
   if (needs_x) CTR_REQUIRE(x && ldx > 0, CTR_EINVAL);
-  plan->vec = vec4 ? 4 : 1;
+  // backward: one dword per lane so that a wave's atomic instruction adds to 256
+  // contiguous bytes of a gradient row (the shape that runs at the full memory-side
+  // atomic rate; dwordx4-per-lane would stride the lanes 16 B apart)
+  plan->vec = (vec4 && !backward) ? 4 : 1;
   plan->units = floats / plan->vec;
   plan->bag_floats = bag_floats;
   CTR_REQUIRE(plan->units <= kMaxUnits, CTR_ELIMIT);
@@ -287,39 +385,65 @@ extern "C" int ctr_embed_fwd(const ctr_field_t* fields, int nfields, const float
   Plan plan;
   int rc = make_plan(fields, nfields, x, ldx, out, ldo, false, &plan);
   if (rc != CTR_OK) return rc;
-  CTR_REQUIRE(batch < (1ll << 31), CTR_ELIMIT);
-  const int grid = ctr_stream_grid(batch * plan.units, kBlock);
   hipStream_t st = (hipStream_t)stream;
+  if (try_fast_ids(fields, nfields, batch, out, ldo, err_flag, st, &rc)) return rc;
+  CTR_REQUIRE(batch * plan.units < (1ll << 32), CTR_ELIMIT);
+  const CtrFastDiv div = ctr_fastdiv((uint32_t)plan.units);
+  const int grid = ctr_stream_grid(batch * plan.units, kBlock);
   if (plan.vec == 4)
     hipLaunchKernelGGL(embed_fwd_kernel<4>, dim3(grid), dim3(kBlock), 0, st, plan.pack, nfields, x, ldx,
-                       (uint32_t)batch, out, ldo, err_flag);
+                       (uint32_t)batch, out, ldo, err_flag, div);
   else
     hipLaunchKernelGGL(embed_fwd_kernel<1>, dim3(grid), dim3(kBlock), 0, st, plan.pack, nfields, x, ldx,
-                       (uint32_t)batch, out, ldo, err_flag);
+                       (uint32_t)batch, out, ldo, err_flag, div);
   return ctr_launch_status();
 }
 
 extern "C" int ctr_embed_bwd(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch,
-                             const float* gout, int64_t ldo, void* stream) {
+                             const float* gout, int64_t ldo, float* workspace, int64_t workspace_floats,
+                             void* stream) {
   CTR_REQUIRE(batch >= 0, CTR_EINVAL);
   if (batch == 0) return CTR_OK;
   CTR_REQUIRE(ldo > 0, CTR_EINVAL);
   Plan plan;
   int rc = make_plan(fields, nfields, x, ldx, gout, ldo, true, &plan);
   if (rc != CTR_OK) return rc;
-  CTR_REQUIRE(batch < (1ll << 31), CTR_ELIMIT);
+  CTR_REQUIRE(batch * plan.units < (1ll << 32), CTR_ELIMIT);
+  const CtrFastDiv div = ctr_fastdiv((uint32_t)plan.units);
   int grid = ctr_stream_grid(batch * plan.units, kBlock);
-  // every block flushes its LDS bag accumulators with global atomics: keep the
-  // flush small next to the payload
-  const int cap = plan.bag_floats > 4096 ? 256 : 1024;
+  // every workgroup ends with a partial of the bag tables' gradients: with a workspace
+  // they are stored and summed by reduce.hip, otherwise added with (serialising) atomics
+  const bool slabs = plan.bag_floats > 0 && workspace != nullptr;
+  int cap = plan.bag_floats > 4096 ? 256 : 1024;
+  if (slabs) {
+    const int64_t fit = workspace_floats / plan.bag_floats;
+    if (fit < cap) cap = (int)fit;
+  } else if (plan.bag_floats > 0) {
+    cap = plan.bag_floats > 4096 ? 64 : 128;
+  }
+  CTR_REQUIRE(cap >= 1, CTR_ELIMIT);
   if (grid > cap) grid = cap;
   hipStream_t st = (hipStream_t)stream;
   const size_t dyn = (size_t)plan.bag_floats * sizeof(float);
+  float* ws = slabs ? workspace : nullptr;
   if (plan.vec == 4)
     hipLaunchKernelGGL(embed_bwd_kernel<4>, dim3(grid), dim3(kBlock), dyn, st, plan.pack, nfields, x, ldx,
-                       (uint32_t)batch, gout, ldo, plan.bag_floats);
+                       (uint32_t)batch, gout, ldo, plan.bag_floats, div, ws);
   else
     hipLaunchKernelGGL(embed_bwd_kernel<1>, dim3(grid), dim3(kBlock), dyn, st, plan.pack, nfields, x, ldx,
-                       (uint32_t)batch, gout, ldo, plan.bag_floats);
-  return ctr_launch_status();
+                       (uint32_t)batch, gout, ldo, plan.bag_floats, div, ws);
+  rc = ctr_launch_status();
+  if (rc != CTR_OK || !slabs) return rc;
+  CtrSegments segs;
+  segs.n = 0;
+  int64_t off = 0;
+  for (int i = 0; i < nfields; ++i) {
+    const ctr_field_t& f = fields[i];
+    if (f.kind == CTR_FIELD_BAG && f.grad) {
+      const int64_t cnt = (int64_t)f.bag_size * f.width;
+      segs.s[segs.n++] = CtrSegment{off, cnt, f.grad};
+      off += cnt;
+    }
+  }
+  return ctr_reduce_segments(workspace, grid, plan.bag_floats, segs, st);
 }

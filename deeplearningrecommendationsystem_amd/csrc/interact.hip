@@ -215,7 +215,7 @@ template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 fm_wide_bwd_kernel(const Geometry g, const float* __restrict__ emb, int64_t lde, int64_t batch, const WideArgs a,
                    const float* __restrict__ gout, int64_t ldgo, const WideGrads wg, float* __restrict__ gemb,
-                   int64_t ldg, int accumulate) {
+                   int64_t ldg, int accumulate, float* __restrict__ ws) {
   extern __shared__ float lds[];
   __shared__ float s_w[kMaxDense + 1];  // block-level sums for w and b
   float* s_g = lds + g.tb * g.row;      // [tb]
@@ -269,7 +269,9 @@ fm_wide_bwd_kernel(const Geometry g, const float* __restrict__ emb, int64_t lde,
   __syncthreads();
   for (int c = threadIdx.x; c <= a.ndense; c += blockDim.x) {
     const float v = s_w[c];
-    if (c < a.ndense) {
+    if (ws) {
+      ws[(int64_t)blockIdx.x * (a.ndense + 1) + c] = v;  // summed by reduce.hip
+    } else if (c < a.ndense) {
       if (wg.w && v != 0.0f) unsafeAtomicAdd(wg.w + c, v);
     } else if (wg.b && v != 0.0f) {
       unsafeAtomicAdd(wg.b, v);
@@ -322,7 +324,8 @@ template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 ffm_head_bwd_kernel(const Geometry g, const float* __restrict__ emb, int64_t lde, int64_t batch, const PairList pl,
                     const WideArgs a, const float* __restrict__ prob, int64_t ldp, const float* __restrict__ gprob,
-                    int64_t ldgp, const WideGrads wg, float* __restrict__ gemb, int64_t ldg) {
+                    int64_t ldgp, const WideGrads wg, float* __restrict__ gemb, int64_t ldg,
+                    float* __restrict__ ws) {
   extern __shared__ float lds[];
   __shared__ float s_w[kMaxDense + 1];
   __shared__ float s_wsum;
@@ -400,7 +403,9 @@ ffm_head_bwd_kernel(const Geometry g, const float* __restrict__ emb, int64_t lde
   __syncthreads();
   for (int c = threadIdx.x; c <= a.ndense; c += blockDim.x) {
     const float v = s_w[c];
-    if (c < a.ndense) {
+    if (ws) {
+      ws[(int64_t)blockIdx.x * (a.ndense + 1) + c] = v;  // summed by reduce.hip
+    } else if (c < a.ndense) {
       if (wg.w && v != 0.0f) unsafeAtomicAdd(wg.w + c, v);
     } else if (wg.b && v != 0.0f) {
       unsafeAtomicAdd(wg.b, v);
@@ -430,6 +435,24 @@ int check_wide(const WideArgs& a) {
                   a.user_col < a.ldx && a.item_col < a.ldx,
               CTR_EINVAL);
   return CTR_OK;
+}
+
+// the dense-column weight/bias gradients are one (ndense+1)-float partial per workgroup:
+// through the workspace when there is one (stores + reduce.hip), else short atomic chains
+inline float* small_grad_workspace(float* workspace, int64_t floats, int ndense, bool wanted, int* grid) {
+  if (*grid > 1024) *grid = 1024;
+  if (!wanted) return nullptr;
+  if (workspace && floats >= (int64_t)(*grid) * (ndense + 1)) return workspace;
+  if (*grid > 128) *grid = 128;
+  return nullptr;
+}
+
+inline int reduce_small_grads(const float* ws, int parts, int ndense, float* gw, float* gb, hipStream_t st) {
+  CtrSegments segs;
+  segs.n = 0;
+  if (gw) segs.s[segs.n++] = CtrSegment{0, ndense, gw};
+  if (gb) segs.s[segs.n++] = CtrSegment{ndense, 1, gb};
+  return ctr_reduce_segments(ws, parts, ndense + 1, segs, st);
 }
 
 inline int tile_grid(int64_t batch, int tb) {
@@ -519,7 +542,7 @@ extern "C" int ctr_fm_wide_bwd(const float* emb, int64_t lde, int64_t batch, int
                                const float* user1, int64_t num_users, const float* item1, int64_t num_items,
                                const float* wide_w, const float* wide_b, const float* gout, int64_t ldgo,
                                float* guser1, float* gitem1, float* gwide_w, float* gwide_b, float* gemb, int64_t ldg,
-                               int accumulate, void* stream) {
+                               int accumulate, float* workspace, int64_t workspace_floats, void* stream) {
   CTR_REQUIRE(batch >= 0, CTR_EINVAL);
   if (batch == 0) return CTR_OK;
   CTR_REQUIRE(emb && gout && nvec >= 1 && nvec <= 64 && dim > 0 && ldgo >= 1 && lde >= (int64_t)nvec * dim, CTR_EINVAL);
@@ -533,15 +556,17 @@ extern "C" int ctr_fm_wide_bwd(const float* emb, int64_t lde, int64_t batch, int
   const size_t dyn = (size_t)g.tb * (g.row + 1) * sizeof(float);
   const WideGrads wg{guser1, gitem1, gwide_w, gwide_b};
   int grid = tile_grid(batch, g.tb);
-  if (grid > 1024) grid = 1024;  // each block ends with ndense+1 global atomics
+  float* ws = small_grad_workspace(workspace, workspace_floats, ndense, gwide_w || gwide_b, &grid);
   hipStream_t st = (hipStream_t)stream;
   if (g.vec == 4)
     hipLaunchKernelGGL(fm_wide_bwd_kernel<4>, dim3(grid), dim3(kBlock), dyn, st, g, emb, lde, batch, a, gout, ldgo, wg,
-                       gemb, ldg, accumulate);
+                       gemb, ldg, accumulate, ws);
   else
     hipLaunchKernelGGL(fm_wide_bwd_kernel<1>, dim3(grid), dim3(kBlock), dyn, st, g, emb, lde, batch, a, gout, ldgo, wg,
-                       gemb, ldg, accumulate);
-  return ctr_launch_status();
+                       gemb, ldg, accumulate, ws);
+  rc = ctr_launch_status();
+  if (rc != CTR_OK || !ws) return rc;
+  return reduce_small_grads(ws, grid, ndense, gwide_w, gwide_b, st);
 }
 
 static int make_pairs(const int32_t* pairs, int npairs, int nvec, PairList* pl) {
@@ -589,7 +614,8 @@ extern "C" int ctr_ffm_head_bwd(const float* emb, int64_t lde, int64_t batch, in
                                 int ndense, const float* user1, int64_t num_users, const float* item1,
                                 int64_t num_items, const float* lin_w, const float* lin_b, const float* prob,
                                 int64_t ldp, const float* gprob, int64_t ldgp, float* guser1, float* gitem1,
-                                float* glin_w, float* glin_b, float* gemb, int64_t ldg, void* stream) {
+                                float* glin_w, float* glin_b, float* gemb, int64_t ldg, float* workspace,
+                                int64_t workspace_floats, void* stream) {
   CTR_REQUIRE(batch >= 0, CTR_EINVAL);
   if (batch == 0) return CTR_OK;
   CTR_REQUIRE(emb && prob && gprob && nvec >= 2 && nvec <= 64 && dim > 0 && lde >= (int64_t)nvec * dim, CTR_EINVAL);
@@ -606,15 +632,17 @@ extern "C" int ctr_ffm_head_bwd(const float* emb, int64_t lde, int64_t batch, in
   const size_t dyn = (size_t)g.tb * (g.row + npairs + 2) * sizeof(float);
   const WideGrads wg{guser1, gitem1, glin_w, glin_b};
   int grid = tile_grid(batch, g.tb);
-  if (grid > 1024) grid = 1024;
+  float* ws = small_grad_workspace(workspace, workspace_floats, ndense, glin_w || glin_b, &grid);
   hipStream_t st = (hipStream_t)stream;
   if (g.vec == 4)
     hipLaunchKernelGGL(ffm_head_bwd_kernel<4>, dim3(grid), dim3(kBlock), dyn, st, g, emb, lde, batch, pl, a, prob, ldp,
-                       gprob, ldgp, wg, gemb, ldg);
+                       gprob, ldgp, wg, gemb, ldg, ws);
   else
     hipLaunchKernelGGL(ffm_head_bwd_kernel<1>, dim3(grid), dim3(kBlock), dyn, st, g, emb, lde, batch, pl, a, prob, ldp,
-                       gprob, ldgp, wg, gemb, ldg);
-  return ctr_launch_status();
+                       gprob, ldgp, wg, gemb, ldg, ws);
+  rc = ctr_launch_status();
+  if (rc != CTR_OK || !ws) return rc;
+  return reduce_small_grads(ws, grid, ndense, glin_w, glin_b, st);
 }
 
 extern "C" int ctr_act_bwd(const float* y, int64_t ldy, const float* gy, int64_t ldgy, float* out, int64_t ldo,

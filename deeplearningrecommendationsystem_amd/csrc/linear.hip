@@ -95,6 +95,16 @@ struct StoreEpi {
     *q = accumulate ? *q + acc : acc;
   }
 };
+// dW pass with many row chunks: chunk z stores its partial tile into slab z of the
+// workspace with plain stores; reduce.hip sums the slabs (fixed order, no atomics)
+struct SlabEpi {
+  float* ws;
+  int64_t ld;
+  int64_t slab_stride;
+  __device__ __forceinline__ void operator()(int64_t i, int64_t j, float acc) const {
+    ws[(int64_t)blockIdx.z * slab_stride + i * ld + j] = acc;
+  }
+};
 struct AtomicEpi {
   float* p;
   int64_t ld;
@@ -164,7 +174,8 @@ __device__ __forceinline__ void read_frag(const float* lds, int r, int h, float 
 template <int NT, int AMODE, int BMODE, class ASrc, class BSrc, class Epi>
 __global__ void __launch_bounds__(kThreads)
 gemm_tile_kernel(const ASrc a, const BSrc b, const Epi epi, int64_t M, int N, int64_t K, int64_t k_chunk,
-                 float* __restrict__ bias_grad /* dW pass only: column sums of A */) {
+                 float* __restrict__ bias_grad /* dW pass only: column sums of A */,
+                 int64_t bias_slab_stride /* 0: atomics into bias_grad, else slab z of it */) {
   constexpr int BN = 32 * NT;
   using AStage = Stager<AMODE, kBM, ASrc>;
   using BStage = Stager<BMODE, BN, BSrc>;
@@ -232,7 +243,12 @@ gemm_tile_kernel(const ASrc a, const BSrc b, const Epi epi, int64_t M, int N, in
   }
   if (bias_grad != nullptr && blockIdx.y == 0 && AMODE == KS && threadIdx.x < kBM) {
     const int64_t i = i0 + threadIdx.x;
-    if (i < M) unsafeAtomicAdd(bias_grad + i, colsum);
+    if (i < M) {
+      if (bias_slab_stride)
+        bias_grad[(int64_t)blockIdx.z * bias_slab_stride + i] = colsum;
+      else
+        unsafeAtomicAdd(bias_grad + i, colsum);
+    }
   }
 }
 
@@ -248,9 +264,15 @@ inline PlainSrc plain(const float* p, int64_t ld, int64_t rows, int64_t cols) {
 
 inline int pick_nt(int n) { return n <= 32 ? 1 : (n <= 64 ? 2 : 4); }
 
+// contraction chunks the launch really makes (chunks are whole 32-deep steps)
+inline int effective_splits(int64_t K, int64_t splits) {
+  const int64_t k_chunk = ctr_ceil_div(ctr_ceil_div(K, splits), kBK) * kBK;
+  return (int)ctr_ceil_div(K, k_chunk);
+}
+
 template <int AMODE, int BMODE, class ASrc, class BSrc, class Epi>
 int launch(const ASrc& a, const BSrc& b, const Epi& e, int64_t M, int N, int64_t K, int splits, float* bias_grad,
-           hipStream_t st) {
+           hipStream_t st, int64_t bias_slab_stride = 0) {
   const int nt = pick_nt(N);
   const int64_t k_chunk = ctr_ceil_div(ctr_ceil_div(K, splits), kBK) * kBK;
   const int zs = (int)ctr_ceil_div(K, k_chunk);
@@ -259,15 +281,15 @@ int launch(const ASrc& a, const BSrc& b, const Epi& e, int64_t M, int N, int64_t
   switch (nt) {
     case 1:
       hipLaunchKernelGGL((gemm_tile_kernel<1, AMODE, BMODE, ASrc, BSrc, Epi>), grid, dim3(kThreads), 0, st, a, b, e, M,
-                         N, K, k_chunk, bias_grad);
+                         N, K, k_chunk, bias_grad, bias_slab_stride);
       break;
     case 2:
       hipLaunchKernelGGL((gemm_tile_kernel<2, AMODE, BMODE, ASrc, BSrc, Epi>), grid, dim3(kThreads), 0, st, a, b, e, M,
-                         N, K, k_chunk, bias_grad);
+                         N, K, k_chunk, bias_grad, bias_slab_stride);
       break;
     default:
       hipLaunchKernelGGL((gemm_tile_kernel<4, AMODE, BMODE, ASrc, BSrc, Epi>), grid, dim3(kThreads), 0, st, a, b, e, M,
-                         N, K, k_chunk, bias_grad);
+                         N, K, k_chunk, bias_grad, bias_slab_stride);
       break;
   }
   return ctr_launch_status();
@@ -291,7 +313,8 @@ extern "C" int ctr_linear_fwd(const float* x, int64_t ldx, const float* w, int64
 
 extern "C" int ctr_linear_bwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* y, int64_t ldy,
                               const float* gy, int64_t ldgy, float* gx, int64_t ldgx, int accumulate_gx, float* gw,
-                              int64_t ldgw, float* gb, int64_t m, int n, int k, int act, void* stream) {
+                              int64_t ldgw, float* gb, int64_t m, int n, int k, int act, float* workspace,
+                              int64_t workspace_floats, void* stream) {
   CTR_REQUIRE(m >= 0 && n > 0 && k > 0, CTR_EINVAL);
   if (m == 0) return CTR_OK;
   CTR_REQUIRE(gy && ldgy >= n, CTR_EINVAL);
@@ -303,7 +326,8 @@ extern "C" int ctr_linear_bwd(const float* x, int64_t ldx, const float* w, int64
   if (m == 0) return CTR_OK;
   hipStream_t st = (hipStream_t)stream;
   if (n == 1 && ctr_n1_supported(k) && (gx || gw || gb))
-    return ctr_n1_bwd(x, ldx, w, y, ldy, gy, ldgy, gx, ldgx, accumulate_gx, gw, gb, m, k, act, st);
+    return ctr_n1_bwd(x, ldx, w, y, ldy, gy, ldgy, gx, ldgx, accumulate_gx, gw, gb, m, k, act, workspace,
+                      workspace_floats, st);
   GzSrc gz;
   gz.gy = plain(gy, ldgy, m, n);
   gz.y = plain(y ? y : gy, y ? ldy : ldgy, m, n);
@@ -321,16 +345,44 @@ extern "C" int ctr_linear_bwd(const float* x, int64_t ldx, const float* w, int64
     int64_t splits = (1024 + tiles - 1) / tiles;           // ~4 workgroups per CU
     const int64_t max_splits = ctr_ceil_div(m, 4 * kBK);   // at least 128 rows each
     if (splits > max_splits) splits = max_splits;
+    if (splits > 256) splits = 256;
     if (splits < 1) splits = 1;
-    if (gw) {
-      AtomicEpi e{gw, ldgw};
-      int rc = launch<KS, KS>(gzt, plain(x, ldx, m, k), e, n, k, m, (int)splits, gb, st);
-      if (rc != CTR_OK) return rc;
-    } else {
-      // bias only: run the same pass over a 1-column slice of X with the output dropped
-      static_assert(sizeof(float) == 4, "");
-      return CTR_EINVAL;  // gb without gw is not used by any model
+    CTR_REQUIRE(gw != nullptr, CTR_EINVAL);  // gb without gw is not used by any model
+    // every chunk adds its partial to the same n*k outputs.  More than a handful of
+    // chunks -> per-chunk slabs in the workspace + one reduction pass; same-address
+    // atomic chains are serialised by the memory side (~60 ns per link)
+    const int64_t slab = (int64_t)n * k;
+    if (workspace && splits > 8) {
+      // as many row chunks as the workspace has slabs for
+      const int64_t fit = workspace_floats / (slab + n);
+      if (fit >= 8 && splits > fit) splits = fit;
     }
+    splits = effective_splits(m, splits);
+    const int64_t need = splits * (slab + n);
+    if (splits > 8 && workspace && workspace_floats >= need) {
+      float* ws_b = workspace + splits * slab;
+      SlabEpi e{workspace, k, slab};
+      int rc = launch<KS, KS>(gzt, plain(x, ldx, m, k), e, n, k, m, (int)splits, gb ? ws_b : nullptr, st, n);
+      if (rc != CTR_OK) return rc;
+      CtrSegments segs;
+      segs.n = 0;
+      if (ldgw == k) {
+        segs.s[segs.n++] = CtrSegment{0, slab, gw};
+      } else {
+        CTR_REQUIRE(n + 1 <= CTR_MAX_SEGMENTS, CTR_ELIMIT);
+        for (int r = 0; r < n; ++r) segs.s[segs.n++] = CtrSegment{(int64_t)r * k, k, gw + r * ldgw};
+      }
+      rc = ctr_reduce_segments(workspace, (int)splits, slab, segs, st);
+      if (rc != CTR_OK || !gb) return rc;
+      CtrSegments bsegs;
+      bsegs.n = 1;
+      bsegs.s[0] = CtrSegment{0, n, gb};
+      return ctr_reduce_segments(ws_b, (int)splits, n, bsegs, st);
+    }
+    if (splits > 64) splits = 64;  // no workspace: keep the same-address atomic chains short
+    AtomicEpi e{gw, ldgw};
+    int rc = launch<KS, KS>(gzt, plain(x, ldx, m, k), e, n, k, m, (int)splits, gb, st);
+    if (rc != CTR_OK) return rc;
   }
   return CTR_OK;
 }

@@ -57,6 +57,7 @@ struct N1BwdArgs {
   float* gx; int64_t ldgx; int accumulate_gx;
   float* gw; float* gb;
   int64_t m; int k; int act; int lpr;
+  float* ws;  // per-workgroup partials [gridDim.x][k+1] (weights then bias), or NULL -> atomics
 };
 
 template <int VEC>
@@ -121,20 +122,26 @@ __global__ void __launch_bounds__(kBlock) n1_bwd_kernel(const N1BwdArgs a) {
           for (int v = 0; v < VEC; ++v) {
             float t = 0.0f;
             for (int g = 0; g < ngroups; ++g) t += s_red[(g * a.lpr + threadIdx.x) * VEC + v];
-            if (t != 0.0f) unsafeAtomicAdd(a.gw + c + v, t);
+            if (a.ws)
+              a.ws[(int64_t)blockIdx.x * (a.k + 1) + c + v] = t;
+            else if (t != 0.0f)
+              unsafeAtomicAdd(a.gw + c + v, t);
           }
         }
       }
     }
   }
-  if (a.gb) {
+  if (a.gb || a.ws) {
     __syncthreads();
     s_red[threadIdx.x] = bacc;
     __syncthreads();
     if (threadIdx.x == 0) {
       float t = 0.0f;
       for (int g = 0; g < kBlock; ++g) t += s_red[g];
-      if (t != 0.0f) unsafeAtomicAdd(a.gb, t);
+      if (a.ws)
+        a.ws[(int64_t)blockIdx.x * (a.k + 1) + a.k] = t;
+      else if (t != 0.0f)
+        unsafeAtomicAdd(a.gb, t);
     }
   }
 }
@@ -166,19 +173,27 @@ int ctr_n1_fwd(const float* x, int64_t ldx, const float* w, const float* bias, c
 
 int ctr_n1_bwd(const float* x, int64_t ldx, const float* w, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
                float* gx, int64_t ldgx, int accumulate_gx, float* gw, float* gb, int64_t m, int k, int act,
-               hipStream_t st) {
+               float* ws, int64_t ws_floats, hipStream_t st) {
   const bool vec = k % 4 == 0 && (!x || (ldx % 4 == 0 && ctr_aligned16(x))) && (!w || ctr_aligned16(w)) &&
                    (!gx || (ldgx % 4 == 0 && ctr_aligned16(gx)));
   const int units = vec ? k / 4 : k;
   int lpr = pow2_ceil(units);
   if (lpr > 64) lpr = 64;
   if ((vec ? 4 : 1) * lpr * kMaxChunks < k) return CTR_ELIMIT;
-  N1BwdArgs a{x, ldx, w, y, ldy, gy, ldgy, gx, ldgx, accumulate_gx, gw, gb, m, k, act, lpr};
   int grid = ctr_stream_grid(m * lpr, kBlock);
-  if (grid > 1024) grid = 1024;  // k+1 atomics per workgroup at the end
+  if (grid > 1024) grid = 1024;
+  const bool slabs = gw && ws && ws_floats >= (int64_t)grid * (k + 1) && grid > 8;
+  if (!slabs && grid > 128) grid = 128;  // same-address atomics serialise: keep the chains short
+  N1BwdArgs a{x, ldx, w, y, ldy, gy, ldgy, gx, ldgx, accumulate_gx, gw, gb, m, k, act, lpr, slabs ? ws : nullptr};
   if (vec)
     hipLaunchKernelGGL(n1_bwd_kernel<4>, dim3(grid), dim3(kBlock), 0, st, a);
   else
     hipLaunchKernelGGL(n1_bwd_kernel<1>, dim3(grid), dim3(kBlock), 0, st, a);
-  return ctr_launch_status();
+  int rc = ctr_launch_status();
+  if (rc != CTR_OK || !slabs) return rc;
+  CtrSegments segs;
+  segs.n = gb ? 2 : 1;
+  segs.s[0] = CtrSegment{0, k, gw};
+  segs.s[1] = CtrSegment{k, 1, gb};
+  return ctr_reduce_segments(ws, grid, k + 1, segs, st);
 }

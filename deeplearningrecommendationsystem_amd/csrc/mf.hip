@@ -37,15 +37,16 @@ mf_fwd_kernel(const float* __restrict__ ut, int64_t nu, const float* __restrict_
   }
 }
 
-template <int VEC>
+// backward: one dword per lane, `group` lanes per sample, so each atomic
+// wave-instruction adds to contiguous 4*group-byte runs of gradient rows
 __global__ void __launch_bounds__(kBlock)
-mf_bwd_kernel(const float* __restrict__ ut, int64_t nu, const float* __restrict__ it, int64_t ni, int dim,
+mf_bwd_kernel(const float* __restrict__ ut, int64_t nu, const float* __restrict__ it, int64_t ni, int dim, int group,
               const int64_t* __restrict__ uidx, const int64_t* __restrict__ iidx, int64_t batch,
               const float* __restrict__ prob, const float* __restrict__ gprob, float* __restrict__ gu,
               float* __restrict__ gi) {
-  const int lane = threadIdx.x & (kGroup - 1);
-  const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / kGroup;
-  for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kGroup; b < batch; b += groups) {
+  const int lane = threadIdx.x % group;
+  const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / group;
+  for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / group; b < batch; b += groups) {
     int64_t u = uidx[b], i = iidx[b];
     if (u < 0 || u >= nu) u = 0;
     if (i < 0 || i >= ni) i = 0;
@@ -53,26 +54,9 @@ mf_bwd_kernel(const float* __restrict__ ut, int64_t nu, const float* __restrict_
     const float dz = gprob[b] * p * (1.0f - p);
     const float* up = ut + u * dim;
     const float* ip = it + i * dim;
-    if (VEC == 4) {
-      for (int e = lane * 4; e < dim; e += kGroup * 4) {
-        const float4 a = *reinterpret_cast<const float4*>(up + e);
-        const float4 c = *reinterpret_cast<const float4*>(ip + e);
-        if (gu) {
-          float* g = gu + u * dim + e;
-          unsafeAtomicAdd(g + 0, dz * c.x); unsafeAtomicAdd(g + 1, dz * c.y);
-          unsafeAtomicAdd(g + 2, dz * c.z); unsafeAtomicAdd(g + 3, dz * c.w);
-        }
-        if (gi) {
-          float* g = gi + i * dim + e;
-          unsafeAtomicAdd(g + 0, dz * a.x); unsafeAtomicAdd(g + 1, dz * a.y);
-          unsafeAtomicAdd(g + 2, dz * a.z); unsafeAtomicAdd(g + 3, dz * a.w);
-        }
-      }
-    } else {
-      for (int e = lane; e < dim; e += kGroup) {
-        if (gu) unsafeAtomicAdd(gu + u * dim + e, dz * ip[e]);
-        if (gi) unsafeAtomicAdd(gi + i * dim + e, dz * up[e]);
-      }
+    for (int e = lane; e < dim; e += group) {
+      if (gu) unsafeAtomicAdd(gu + u * dim + e, dz * ip[e]);
+      if (gi) unsafeAtomicAdd(gi + i * dim + e, dz * up[e]);
     }
   }
 }
@@ -113,14 +97,10 @@ extern "C" int ctr_mf_bwd(const float* user_table, int64_t num_users, const floa
   if (rc != CTR_OK) return rc;
   if (batch == 0) return CTR_OK;
   CTR_REQUIRE(prob && gprob, CTR_EINVAL);
-  const bool v4 = dim % 4 == 0 && ctr_aligned16(user_table) && ctr_aligned16(item_table);
-  const int grid = ctr_stream_grid(batch * kGroup, kBlock);
-  hipStream_t st = (hipStream_t)stream;
-  if (v4)
-    hipLaunchKernelGGL(mf_bwd_kernel<4>, dim3(grid), dim3(kBlock), 0, st, user_table, num_users, item_table,
-                       num_items, dim, user_idx, item_idx, batch, prob, gprob, guser, gitem);
-  else
-    hipLaunchKernelGGL(mf_bwd_kernel<1>, dim3(grid), dim3(kBlock), 0, st, user_table, num_users, item_table,
-                       num_items, dim, user_idx, item_idx, batch, prob, gprob, guser, gitem);
+  int group = 1;
+  while (group < dim && group < 64) group <<= 1;
+  const int grid = ctr_stream_grid(batch * group, kBlock);
+  hipLaunchKernelGGL(mf_bwd_kernel, dim3(grid), dim3(kBlock), 0, (hipStream_t)stream, user_table, num_users, item_table,
+                     num_items, dim, group, user_idx, item_idx, batch, prob, gprob, guser, gitem);
   return ctr_launch_status();
 }

@@ -95,14 +95,15 @@ class DeepCrossing(FeatureModel):
         tables, (lin_w, lin_b) = params[:5], params[5:7]
         batch, e = x.shape[0], tables[0].shape[1]
         width = 5 * e + 1
-        g_lin_w, g_lin_b = torch.zeros_like(lin_w), torch.zeros_like(lin_b)
+        zeros = ops.zero_grads(params)
+        g_lin_w, g_lin_b = zeros[id(lin_w)], zeros[id(lin_b)]
         gr = self._stack_buffer(batch, width, x.device)
         ops.linear_bwd(rs[-1], lin_w, prob, gprob, ACT_SIGMOID, gr, g_lin_w, g_lin_b)
         block_grads = []
         for k in range(len(self.res_layers) - 1, -1, -1):
             w1, b1, w2, b2 = params[7 + 4 * k: 11 + 4 * k]
             r_in, r_out, h = rs[k], rs[k + 1], hs[k]
-            gw1, gb1, gw2, gb2 = (torch.zeros_like(t) for t in (w1, b1, w2, b2))
+            gw1, gb1, gw2, gb2 = (zeros[id(t)] for t in (w1, b1, w2, b2))
             gh = torch.empty_like(h)
             ops.linear_bwd(h, w2, r_out, gr, ACT_RELU, gh, gw2, gb2)            # through relu(linear2(h)+r)
             gr_in = self._stack_buffer(batch, width, x.device)
@@ -110,7 +111,7 @@ class DeepCrossing(FeatureModel):
             ops.act_bwd(r_out, gr, ACT_RELU, gr_in, accumulate=True)            # the skip connection
             gr = gr_in
             block_grads.append((gw1, gb1, gw2, gb2))
-        tgrads = {id(t): torch.zeros_like(t) for t in tables}
+        tgrads = zeros
         ops.embed_bwd(self._specs(tables, e), x, batch, gr, tgrads)
         grads = [tgrads[id(t)] for t in tables] + [g_lin_w, g_lin_b]
         for bg in reversed(block_grads):

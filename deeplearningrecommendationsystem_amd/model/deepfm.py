@@ -92,16 +92,16 @@ class DeepFM(FeatureModel):
         user1, item1, wide_w, wide_b, out_w, out_b = params[6:12]
         batch, dim = x.shape[0], tables[0].shape[1]
         layers = self._layers(params)
+        zeros = ops.zero_grads(params)
         gcomb = torch.empty_like(comb)
-        g_out_w, g_out_b = torch.zeros_like(out_w), torch.zeros_like(out_b)
+        g_out_w, g_out_b = zeros[id(out_w)], zeros[id(out_b)]
         ops.linear_bwd(comb, out_w, prob, gprob, ACT_SIGMOID, gcomb, g_out_w, g_out_b)
         gemb = torch.empty_like(emb)
-        layer_grads, _ = ops.mlp_bwd(acts, layers, gcomb[:, 1:], gemb)
-        g_user1, g_item1 = torch.zeros_like(user1), torch.zeros_like(item1)
-        g_wide_w, g_wide_b = torch.zeros_like(wide_w), torch.zeros_like(wide_b)
+        layer_grads, _ = ops.mlp_bwd(acts, layers, gcomb[:, 1:], gemb, zeros=zeros)
+        g_user1, g_item1, g_wide_w, g_wide_b = (zeros[id(t)] for t in (user1, item1, wide_w, wide_b))
         ops.fm_wide_bwd(emb, 6, dim, x, user1, item1, wide_w, wide_b, gcomb[:, 0:1], g_user1, g_item1,
                         g_wide_w, g_wide_b, gemb, accumulate=True)
-        tgrads = {id(t): torch.zeros_like(t) for t in tables}
+        tgrads = zeros
         ops.embed_bwd(six_field_specs(tables, dim), x, batch, gemb, tgrads)
         grads = [tgrads[id(t)] for t in tables] + [g_user1, g_item1, g_wide_w, g_wide_b, g_out_w, g_out_b]
         for gw, gb in layer_grads:

@@ -80,11 +80,12 @@ class DIEN(SequenceModel):
         dim = table.shape[1]
         dev = table.device
         c = att_acts[0]
-        fc_grads, gfcin = ops.mlp_bwd(fc_acts, fc, gprob, None)
+        zeros = ops.zero_grads(params)
+        fc_grads, gfcin = ops.mlp_bwd(fc_acts, fc, gprob, None, zeros=zeros)
         dgi = torch.empty((batch * length, 3 * dim), dtype=torch.float32, device=dev)
         dgh = torch.empty((batch * (length + 1), 3 * dim), dtype=torch.float32, device=dev)
         ops.gru_bwd(gi, w_hh, b_hh, hbuf, batch, length, dim, gfcin[:, :dim], dgi, dgh)
-        g_w_ih, g_w_hh, g_b_ih, g_b_hh = (torch.zeros_like(t) for t in (w_ih, w_hh, b_ih, b_hh))
+        g_w_ih, g_w_hh, g_b_ih, g_b_hh = (zeros[id(t)] for t in (w_ih, w_hh, b_ih, b_hh))
         gseq = torch.empty_like(seq)
         ops.linear_bwd(seq, w_ih, None, dgi, ACT_NONE, gseq, g_w_ih, g_b_ih)
         # dW_hh = sum_{b,t} dgh_t (x) h_{t-1}: rows r+1 of dgh against rows r of hbuf; the
@@ -94,8 +95,8 @@ class DIEN(SequenceModel):
             ops.linear_bwd(hbuf[:rows], w_hh, None, dgh[1:], ACT_NONE, None, g_w_hh, g_b_hh)
         gscore = torch.empty((batch * length, 1), dtype=torch.float32, device=dev)
         ops.din_pool_bwd(attn, c, batch, length, dim, gseq, False, gscore)
-        att_grads, gc = ops.mlp_bwd(att_acts, att, gscore, None)
-        gtable = torch.zeros_like(table)
+        att_grads, gc = ops.mlp_bwd(att_acts, att, gscore, None, zeros=zeros)
+        gtable = zeros[id(table)]
         ops.din_concat_bwd(hist, target, table.shape[0], dim, gc, attn, gseq, False, gfcin[:, dim:], gtable)
         grads = [gtable]
         for gw, gb in att_grads + fc_grads:

@@ -97,11 +97,12 @@ class DIN(SequenceModel):
         batch, length = hist.shape
         dim = table.shape[1]
         c, fcin = att_acts[0], fc_acts[0]
-        fc_grads, gfcin = ops.mlp_bwd(fc_acts, fc, gprob, None)
+        zeros = ops.zero_grads(params)
+        fc_grads, gfcin = ops.mlp_bwd(fc_acts, fc, gprob, None, zeros=zeros)
         gscore = torch.empty((batch * length, 1), dtype=torch.float32, device=table.device)
         ops.din_pool_bwd(attn, c, batch, length, dim, gfcin[:, :dim], True, gscore)
-        att_grads, gc = ops.mlp_bwd(att_acts, att, gscore, None)
-        gtable = torch.zeros_like(table)
+        att_grads, gc = ops.mlp_bwd(att_acts, att, gscore, None, zeros=zeros)
+        gtable = zeros[id(table)]
         ops.din_concat_bwd(hist, target, table.shape[0], dim, gc, attn, gfcin[:, :dim], True, gfcin[:, dim:], gtable)
         grads = [gtable]
         for gw, gb in att_grads + fc_grads:

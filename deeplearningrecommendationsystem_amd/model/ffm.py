@@ -75,10 +75,11 @@ class FFM(FeatureModel):
         tables, (user1, item1, lin_w, lin_b) = params[:12], params[12:16]
         batch, dim = x.shape[0], tables[0].shape[1]
         gemb = torch.empty_like(emb)
-        g_user1, g_item1, g_w, g_b = (torch.zeros_like(t) for t in (user1, item1, lin_w, lin_b))
+        zeros = ops.zero_grads(params)
+        g_user1, g_item1, g_w, g_b = (zeros[id(t)] for t in (user1, item1, lin_w, lin_b))
         ops.ffm_head_bwd(emb, 12, dim, PAIRS, x, user1, item1, lin_w, lin_b, prob, gprob.view(batch, 1),
                          g_user1, g_item1, g_w, g_b, gemb)
-        tgrads = {id(t): torch.zeros_like(t) for t in tables}
+        tgrads = zeros
         ops.embed_bwd(self._specs(tables, dim), x, batch, gemb, tgrads)
         return [tgrads[id(t)] for t in tables] + [g_user1, g_item1, g_w, g_b]
 

@@ -19,8 +19,9 @@ class _MFFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gprob):
         user_table, item_table, user_idx, item_idx, prob = ctx.saved_tensors
-        gu = torch.zeros_like(user_table) if ctx.needs_input_grad[0] else None
-        gi = torch.zeros_like(item_table) if ctx.needs_input_grad[1] else None
+        zeros = ops.zero_grads([user_table, item_table])
+        gu = zeros[id(user_table)] if ctx.needs_input_grad[0] else None
+        gi = zeros[id(item_table)] if ctx.needs_input_grad[1] else None
         ops.mf_bwd(user_table, item_table, user_idx, item_idx, prob, gprob.contiguous(), gu, gi)
         return gu, gi, None, None, None
 

@@ -51,14 +51,15 @@ class _NeuralCFFunction(torch.autograd.Function):
         proj = Layer(dense[2 * n_hidden], dense[2 * n_hidden + 1], ACT_NONE)
         head = Layer(dense[2 * n_hidden + 2], dense[2 * n_hidden + 3], ACT_SIGMOID)
 
+        tables = (gmf_u, gmf_i, mlp_u, mlp_i)
+        zeros = ops.zero_grads(list(tables) + list(dense))
         gbuf = torch.empty_like(buf)
-        g_head_w, g_head_b = torch.zeros_like(head.weight), torch.zeros_like(head.bias)
+        g_head_w, g_head_b = zeros[id(head.weight)], zeros[id(head.bias)]
         ops.linear_bwd(buf[:, l0:], head.weight, prob, gprob.contiguous(), ACT_SIGMOID, gbuf[:, l0:],
                        g_head_w, g_head_b)
         acts = [buf[:, :l0]] + mids + [buf[:, l0 + mf:]]
-        layer_grads, _ = ops.mlp_bwd(acts, hidden + [proj], gbuf[:, l0 + mf:], gbuf[:, :l0])
-        tables = (gmf_u, gmf_i, mlp_u, mlp_i)
-        tgrads = {id(t): torch.zeros_like(t) for t in tables}
+        layer_grads, _ = ops.mlp_bwd(acts, hidden + [proj], gbuf[:, l0 + mf:], gbuf[:, :l0], zeros=zeros)
+        tgrads = zeros
         ops.embed_bwd(_specs(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i), None, batch, gbuf, tgrads)
         out = [None, None, None, None] + [tgrads[id(t)] for t in tables]
         for gw, gb in layer_grads:

@@ -109,8 +109,9 @@ class PNN(FeatureModel):
         w1, b1, w2, b2 = params[6:10]
         batch, dim = x.shape[0], tables[0].shape[1]
         tail = self._tail(params)
-        tail_grads, gh0 = ops.mlp_bwd(acts, tail, gprob.view(batch, 1), None)
-        gw1, gb1, gw2, gb2 = (torch.zeros_like(t) for t in (w1, b1, w2, b2))
+        zeros = ops.zero_grads(params)
+        tail_grads, gh0 = ops.mlp_bwd(acts, tail, gprob.view(batch, 1), None, zeros=zeros)
+        gw1, gb1, gw2, gb2 = (zeros[id(t)] for t in (w1, b1, w2, b2))
         gemb = torch.empty_like(emb)
         ops.linear_bwd(emb, w1, None, gh0, ACT_NONE, gemb, gw1, gb1)
         if self.product.model == "in":
@@ -125,7 +126,7 @@ class PNN(FeatureModel):
             gs = ops.linear_fwd(s, gprod, None)                                     # S gp^T
             ops.linear_bwd(s, gprod, None, s, ACT_NONE, gs, None, None, accumulate_gx=True)   # += S gp
             ops.linear_bwd(emb, self._sum_selector, None, gs, ACT_NONE, gemb, None, None, accumulate_gx=True)
-        tgrads = {id(t): torch.zeros_like(t) for t in tables}
+        tgrads = zeros
         ops.embed_bwd(six_field_specs(tables, dim), x, batch, gemb, tgrads)
         grads = [tgrads[id(t)] for t in tables] + [gw1, gb1, gw2, gb2, tail_grads[-1][0], tail_grads[-1][1]]
         for gw, gb in tail_grads[:-1]:

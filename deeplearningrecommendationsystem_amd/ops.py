@@ -95,6 +95,16 @@ def _embed_bytes(specs, batch, backward):
     return batch * (out + idx + xcols + prod_rows + 2 * rows) + 2 * small
 
 
+SCRATCH_FLOATS = 16 * 1024 * 1024  # 64 MiB: per-workgroup partials of the weight-gradient reductions
+
+
+def _scratch(device) -> torch.Tensor:
+    """device scratch for one backward launch.  Taken from torch's caching allocator per
+    call (a few microseconds, no hipMalloc in steady state), so it follows the usual
+    stream-ordered lifetime rules instead of being shared global state."""
+    return torch.empty(SCRATCH_FLOATS, dtype=torch.float32, device=device)
+
+
 def _mat(t: torch.Tensor, what: str) -> torch.Tensor:
     if t.dim() != 2 or t.dtype != torch.float32 or (t.shape[1] > 1 and t.stride(1) != 1):
         raise ValueError(f"{what}: expected a 2-D float32 tensor with unit inner stride, got "
@@ -174,9 +184,10 @@ def embed_bwd(specs: Sequence[FieldSpec], x: Optional[torch.Tensor], batch: int,
     if x is not None:
         x = _mat(x, "x")
     arr = _field_array(specs, grads)
+    ws = _scratch(gout.device) if any(s.kind == FIELD_BAG for s in specs) else None
     rc = _timed("embed_bwd", lambda: (_embed_bytes(specs, batch, True), 0),
                 _lib.load().ctr_embed_bwd, arr, len(specs), _lib.ptr(x), _ld(x) if x is not None else 0, batch,
-                gout.data_ptr(), _ld(gout), _lib.stream_ptr())
+                gout.data_ptr(), _ld(gout), _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream_ptr())
     _lib.check(rc, "ctr_embed_bwd")
 
 
@@ -215,11 +226,13 @@ def linear_bwd(x: torch.Tensor, w: torch.Tensor, y: Optional[torch.Tensor], gy: 
         gx = _mat(gx, "gx")
     fn = _lib.load().ctr_linear_bwd
     ygy = 4 * m * n * (2 if (y is not None and act != ACT_NONE) else 1)
+    ws = _scratch(x.device) if gw is not None else None
 
     def call(gx_, gw_, gb_):
         return (x.data_ptr(), _ld(x), w.data_ptr(), _ld(w), _lib.ptr(y), _ld(y) if y is not None else 0,
                 gy.data_ptr(), _ld(gy), _lib.ptr(gx_), _ld(gx_) if gx_ is not None else 0, int(accumulate_gx),
-                _lib.ptr(gw_), _ld(gw_) if gw_ is not None else 0, _lib.ptr(gb_), m, n, k, act, _lib.stream_ptr())
+                _lib.ptr(gw_), _ld(gw_) if gw_ is not None else 0, _lib.ptr(gb_), m, n, k, act,
+                _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream_ptr())
 
     if _profiler is None:
         _lib.check(fn(*call(gx, gw, gb)), "ctr_linear_bwd")
@@ -265,6 +278,19 @@ class Layer:
     act: int
 
 
+def zero_grads(tensors: Sequence[torch.Tensor]) -> dict:
+    """{id(t): zero tensor shaped like t} for every parameter of a backward pass, carved
+    out of ONE flat buffer so a step issues a single memset instead of one per
+    parameter (each piece starts 16-byte aligned)."""
+    sizes = [(t.numel() + 3) // 4 * 4 for t in tensors]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=tensors[0].device)
+    out, off = {}, 0
+    for t, n in zip(tensors, sizes):
+        out[id(t)] = flat[off:off + t.numel()].view(t.shape)
+        off += n
+    return out
+
+
 def mlp_fwd(x: torch.Tensor, layers: Sequence[Layer], last_out: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
     """returns [x, y_1, ..., y_n]; the last layer may write into ``last_out``"""
     acts = [x]
@@ -275,7 +301,7 @@ def mlp_fwd(x: torch.Tensor, layers: Sequence[Layer], last_out: Optional[torch.T
 
 
 def mlp_bwd(acts: Sequence[torch.Tensor], layers: Sequence[Layer], gy: torch.Tensor,
-            gx_first: Optional[torch.Tensor], want_gx_first: bool = True):
+            gx_first: Optional[torch.Tensor], want_gx_first: bool = True, zeros: Optional[dict] = None):
     """backward through ``mlp_fwd``; returns ([(gw, gb) per layer], gx of the
     first layer input or None)"""
     grads = [None] * len(layers)
@@ -283,8 +309,12 @@ def mlp_bwd(acts: Sequence[torch.Tensor], layers: Sequence[Layer], gy: torch.Ten
     for k in range(len(layers) - 1, -1, -1):
         layer = layers[k]
         xin, yout = acts[k], acts[k + 1]
-        gw = torch.zeros_like(layer.weight)
-        gb = torch.zeros_like(layer.bias) if layer.bias is not None else None
+        if zeros is not None:
+            gw = zeros[id(layer.weight)]
+            gb = zeros[id(layer.bias)] if layer.bias is not None else None
+        else:
+            gw = torch.zeros_like(layer.weight)
+            gb = torch.zeros_like(layer.bias) if layer.bias is not None else None
         if k > 0:
             gx = torch.empty((xin.shape[0], xin.shape[1]), dtype=torch.float32, device=xin.device)
         else:
@@ -348,12 +378,13 @@ def fm_wide_bwd(emb, nvec, dim, x, user1, item1, wide_w, wide_b, gout, guser1, g
                 accumulate: bool) -> None:
     emb, gout = _mat(emb, "emb"), _mat(gout, "gout")
     batch = emb.shape[0]
+    ws = _scratch(emb.device)
     rc = _timed("fm_wide_bwd", lambda: (4 * batch * ((2 + int(accumulate)) * nvec * dim + 45 + 5),
                                         4 * batch * nvec * dim),
                 _lib.load().ctr_fm_wide_bwd, emb.data_ptr(), _ld(emb), batch, nvec, dim,
                 *_wide_args(x, user1, item1, wide_w, wide_b), gout.data_ptr(), _ld(gout), _lib.ptr(guser1),
                 _lib.ptr(gitem1), _lib.ptr(gwide_w), _lib.ptr(gwide_b), _lib.ptr(gemb),
-                _ld(gemb) if gemb is not None else 0, int(accumulate), _lib.stream_ptr())
+                _ld(gemb) if gemb is not None else 0, int(accumulate), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
     _lib.check(rc, "ctr_fm_wide_bwd")
 
 
@@ -376,11 +407,12 @@ def ffm_head_bwd(emb, nvec, dim, pairs, x, user1, item1, lin_w, lin_b, prob, gpr
                  gemb) -> None:
     emb, prob, gprob, gemb = _mat(emb, "emb"), _mat(prob, "prob"), _mat(gprob, "gprob"), _mat(gemb, "gemb")
     batch = emb.shape[0]
+    ws = _scratch(emb.device)
     rc = _timed("ffm_head_bwd", lambda: (4 * batch * (2 * nvec * dim + 45 + 6), 4 * batch * len(pairs) * dim),
                 _lib.load().ctr_ffm_head_bwd, emb.data_ptr(), _ld(emb), batch, nvec, dim, _pair_array(pairs),
                 len(pairs), *_wide_args(x, user1, item1, lin_w, lin_b), prob.data_ptr(), _ld(prob),
                 gprob.data_ptr(), _ld(gprob), _lib.ptr(guser1), _lib.ptr(gitem1), _lib.ptr(glin_w),
-                _lib.ptr(glin_b), gemb.data_ptr(), _ld(gemb), _lib.stream_ptr())
+                _lib.ptr(glin_b), gemb.data_ptr(), _ld(gemb), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
     _lib.check(rc, "ctr_ffm_head_bwd")
 
 

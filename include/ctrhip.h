@@ -83,9 +83,13 @@ int ctr_embed_fwd(const ctr_field_t* fields, int nfields, const float* x, int64_
 /* backward of ctr_embed_fwd (autograd of the lines above; embedding_dense_backward
  * and the `x^T g` matmul backward, trainer/trainer.py:38): accumulates
  * (+=) into each field's dense `grad`; the caller zero-fills it first when it
- * wants a fresh gradient.  fp32 atomics: order of accumulation is not fixed. */
+ * wants a fresh gradient.  Id rows: fp32 atomics (order of accumulation not
+ * fixed).  Bag tables (every sample hits the same few rows): reduced per
+ * workgroup in LDS, then through `workspace` (device scratch, nullable; see
+ * ctr_linear_bwd) or, without it, by atomics. */
 int ctr_embed_bwd(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx,
-                  int64_t batch, const float* gout, int64_t ldo, void* stream);
+                  int64_t batch, const float* gout, int64_t ldo,
+                  float* workspace, int64_t workspace_floats, void* stream);
 
 /* ------------------------------------------------------------------------
  * Matrix factorisation, fused (model/mf.py:23-26):
@@ -117,12 +121,18 @@ int ctr_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, con
  * gw[n,k] += sum_m gz[m,n] X[m,k]     (skipped when gw == NULL)
  * gb[n]  += sum_m gz[m,n]             (skipped when gb == NULL; needs gw)
  * Autograd of the nn.Linear + activation lines above (trainer/trainer.py:38).
- * gw/gb accumulate with fp32 atomics over row chunks: the caller zero-fills. */
+ * gw/gb are sums over row chunks computed by different workgroups.  With a
+ * `workspace` (device scratch, `workspace_floats` floats, may be NULL; 16M floats
+ * give every layer of the zoo its full parallelism) each chunk stores its partial there and a second
+ * pass adds them in a fixed order (reproducible); without it the chunks accumulate
+ * with fp32 atomics.  Either way the result is ADDED to gw/gb: zero-fill for a
+ * fresh gradient. */
 int ctr_linear_bwd(const float* x, int64_t ldx, const float* w, int64_t ldw,
                    const float* y, int64_t ldy, const float* gy, int64_t ldgy,
                    float* gx, int64_t ldgx, int accumulate_gx,
                    float* gw, int64_t ldgw, float* gb,
-                   int64_t m, int n, int k, int act, void* stream);
+                   int64_t m, int n, int k, int act,
+                   float* workspace, int64_t workspace_floats, void* stream);
 
 /* ------------------------------------------------------------------------
  * Feature interactions on the stacked embedding matrix emb (batch, >= nvec*dim)
@@ -154,7 +164,8 @@ int ctr_fm_wide_bwd(const float* emb, int64_t lde, int64_t batch, int nvec, int 
                     const float* user1, int64_t num_users, const float* item1, int64_t num_items,
                     const float* wide_w, const float* wide_b, const float* gout, int64_t ldgo,
                     float* guser1, float* gitem1, float* gwide_w, float* gwide_b,
-                    float* gemb, int64_t ldg, int accumulate, void* stream);
+                    float* gemb, int64_t ldg, int accumulate,
+                    float* workspace, int64_t workspace_floats, void* stream);
 
 /* FFM head (model/ffm.py:62-86): cross = sum_p <v_a(p), v_b(p)> over the host pair
  * list `pairs` (2*npairs ints, npairs <= 64), summed left to right;
@@ -174,7 +185,8 @@ int ctr_ffm_head_bwd(const float* emb, int64_t lde, int64_t batch, int nvec, int
                      const float* lin_w, const float* lin_b,
                      const float* prob, int64_t ldp, const float* gprob, int64_t ldgp,
                      float* guser1, float* gitem1, float* glin_w, float* glin_b,
-                     float* gemb, int64_t ldg, void* stream);
+                     float* gemb, int64_t ldg,
+                     float* workspace, int64_t workspace_floats, void* stream);
 
 /* out (= or +=) gy * act'(y): the residual branch of model/deepcrossing.py:26 */
 int ctr_act_bwd(const float* y, int64_t ldy, const float* gy, int64_t ldgy, float* out, int64_t ldo,
