@@ -51,6 +51,13 @@ struct PlainSrc {
     }
     return v;
   }
+  // interior tile: no bounds checks, straight-line code the scheduler can slide under MFMAs
+  __device__ __forceinline__ float4 load4_fast(int64_t r, int64_t c) const {
+    return *reinterpret_cast<const float4*>(p + r * ld + c);
+  }
+  __device__ __forceinline__ bool interior(int64_t r0, int64_t nr, int64_t c0, int64_t nc) const {
+    return vec && r0 + nr <= rows && c0 + nc <= cols;
+  }
 };
 
 // gZ = gY * act'(Y), formed on the fly from the saved layer output
@@ -62,6 +69,20 @@ struct GzSrc {
     float4 g = gy.load4(r, c);
     if (act != CTR_ACT_NONE) {
       const float4 o = y.load4(r, c);
+      g.x *= ctr_act_grad(o.x, act);
+      g.y *= ctr_act_grad(o.y, act);
+      g.z *= ctr_act_grad(o.z, act);
+      g.w *= ctr_act_grad(o.w, act);
+    }
+    return g;
+  }
+  __device__ __forceinline__ bool interior(int64_t r0, int64_t nr, int64_t c0, int64_t nc) const {
+    return gy.interior(r0, nr, c0, nc) && (act == CTR_ACT_NONE || y.interior(r0, nr, c0, nc));
+  }
+  __device__ __forceinline__ float4 load4_fast(int64_t r, int64_t c) const {
+    float4 g = gy.load4_fast(r, c);
+    if (act != CTR_ACT_NONE) {
+      const float4 o = y.load4_fast(r, c);
       g.x *= ctr_act_grad(o.x, act);
       g.y *= ctr_act_grad(o.y, act);
       g.z *= ctr_act_grad(o.z, act);
@@ -122,15 +143,31 @@ struct Stager {
   static constexpr int kLdsFloats = MODE == KC ? ROWS * kKcStride : kBK * kKsStride;
   float4 reg[kVecs];
 
-  __device__ __forceinline__ void load(const Src& s, int64_t row0, int64_t k0) {
+  // `fast`: workgroup-uniform, true when the whole tile is inside the matrix and 16-B aligned
+  __device__ __forceinline__ void load(const Src& s, int64_t row0, int64_t k0, bool fast) {
     const int t = threadIdx.x;
+    if (fast) {
+#pragma unroll
+      for (int p = 0; p < kVecs; ++p) {
+        if (MODE == KC) {
+          const int c4 = t & 7, r = (t >> 3) + 32 * p;
+          reg[p] = s.load4_fast(row0 + r, k0 + c4 * 4);
+        } else {
+          constexpr int kPerRow = ROWS / 4;  // float4 per kk row
+          const int v = t + kThreads * p;
+          const int c4 = v % kPerRow, kk = v / kPerRow;
+          reg[p] = s.load4_fast(k0 + kk, row0 + c4 * 4);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < kVecs; ++p) {
       if (MODE == KC) {
         const int c4 = t & 7, r = (t >> 3) + 32 * p;
         reg[p] = s.load4(row0 + r, k0 + c4 * 4);
       } else {
-        constexpr int kPerRow = ROWS / 4;  // float4 per kk row
+        constexpr int kPerRow = ROWS / 4;
         const int v = t + kThreads * p;
         const int c4 = v % kPerRow, kk = v / kPerRow;
         reg[p] = s.load4(k0 + kk, row0 + c4 * 4);
@@ -179,51 +216,76 @@ gemm_tile_kernel(const ASrc a, const BSrc b, const Epi epi, int64_t M, int N, in
   constexpr int BN = 32 * NT;
   using AStage = Stager<AMODE, kBM, ASrc>;
   using BStage = Stager<BMODE, BN, BSrc>;
-  __shared__ __attribute__((aligned(16))) float s_a[AStage::kLdsFloats];
-  __shared__ __attribute__((aligned(16))) float s_b[BStage::kLdsFloats];
+  // two LDS buffers per operand: tile k+1 is written while tile k is multiplied, one
+  // barrier per 32-deep step
+  __shared__ __attribute__((aligned(16))) float s_a[2][AStage::kLdsFloats];
+  __shared__ __attribute__((aligned(16))) float s_b[2][BStage::kLdsFloats];
 
   const int64_t i0 = (int64_t)blockIdx.x * kBM;
   const int64_t j0 = (int64_t)blockIdx.y * BN;
   const int64_t kb = (int64_t)blockIdx.z * k_chunk;
   const int64_t ke = kb + k_chunk < K ? kb + k_chunk : K;
+  const int nk = (int)((ke - kb + kBK - 1) / kBK);
+  const int full = (int)((ke - kb) / kBK);  // steps whose 32 contraction indices all exist
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
 
-  floatx16 acc[NT];
+  // Four independent accumulator chains per wave whatever NT is: consecutive MFMAs never
+  // wait on each other's result.  NT = 4: one chain per column tile; NT = 2 / 1: the
+  // contraction steps are dealt round-robin to 2 / 4 chains per tile, summed at the end.
+  constexpr int CH = 4 / NT;
+  floatx16 acc[NT][CH];
 #pragma unroll
   for (int n = 0; n < NT; ++n)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[n][e] = 0.0f;
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[n][c][e] = 0.0f;
   float colsum = 0.0f;
+
+  // operand tiles that lie wholly inside their matrices take the unguarded load path
+  const bool a_in = AMODE == KC ? a.interior(i0, kBM, 0, 0) : a.interior(0, 0, i0, kBM);
+  const bool b_in = BMODE == KC ? b.interior(j0, BN, 0, 0) : b.interior(0, 0, j0, BN);
 
   AStage sa;
   BStage sb;
-  sa.load(a, i0, kb);
-  sb.load(b, j0, kb);
-  for (int64_t k0 = kb; k0 < ke; k0 += kBK) {
-    sa.store(s_a);
-    sb.store(s_b);
-    __syncthreads();
-    if (k0 + kBK < ke) {
-      sa.load(a, i0, k0 + kBK);
-      sb.load(b, j0, k0 + kBK);
+  sa.load(a, i0, kb, a_in && full > 0);
+  sb.load(b, j0, kb, b_in && full > 0);
+  sa.store(s_a[0]);
+  sb.store(s_b[0]);
+  if (nk > 1) {
+    sa.load(a, i0, kb + kBK, a_in && full > 1);
+    sb.load(b, j0, kb + kBK, b_in && full > 1);
+  }
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < nk) {
+      sa.store(s_a[cur ^ 1]);
+      sb.store(s_b[cur ^ 1]);
+    }
+    if (ks + 2 < nk) {
+      const int64_t k2 = kb + (int64_t)(ks + 2) * kBK;
+      sa.load(a, i0, k2, a_in && ks + 2 < full);
+      sb.load(b, j0, k2, b_in && ks + 2 < full);
     }
     float fa[16];
-    read_frag<AMODE, kBM>(s_a, 32 * wave + r, h, fa);
+    read_frag<AMODE, kBM>(s_a[cur], 32 * wave + r, h, fa);
+    float fb[NT][16];
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      float fb[16];
-      read_frag<BMODE, BN>(s_b, 32 * n + r, h, fb);
+    for (int n = 0; n < NT; ++n) read_frag<BMODE, BN>(s_b[cur], 32 * n + r, h, fb[n]);
 #pragma unroll
-      for (int t = 0; t < 16; ++t) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc[n], 0, 0, 0);
-    }
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        acc[n][t % CH] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[n][t], acc[n][t % CH], 0, 0, 0);
     if (bias_grad != nullptr && blockIdx.y == 0 && AMODE == KS) {
       // A tile is [kk][row]: thread `row` adds its 32 contraction values
       if (threadIdx.x < kBM) {
         constexpr int kKsStride = kBM + 4;
 #pragma unroll 8
-        for (int kk = 0; kk < kBK; ++kk) colsum += s_a[kk * kKsStride + threadIdx.x];
+        for (int kk = 0; kk < kBK; ++kk) colsum += s_a[cur][kk * kKsStride + threadIdx.x];
       }
     }
     __syncthreads();
@@ -237,7 +299,10 @@ gemm_tile_kernel(const ASrc a, const BSrc b, const Epi epi, int64_t M, int N, in
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int64_t i = i0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (i < M) epi(i, j, acc[n][e]);
+        float v = acc[n][0][e];
+#pragma unroll
+        for (int c = 1; c < CH; ++c) v += acc[n][c][e];
+        if (i < M) epi(i, j, v);
       }
     }
   }
