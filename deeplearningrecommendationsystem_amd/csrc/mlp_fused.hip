@@ -1,0 +1,508 @@
+// Whole narrow MLP stacks in ONE launch (forward) / ONE launch (backward).
+//
+// NeuralCF's tower (model/neuralcf.py:48-51: 128 -> 64 -> 32 -> 16 -> 8 -> 64 at
+// BASELINE configs[1]) is 23 kFLOP per sample: as five GEMM launches it is bound by
+// writing and re-reading activations and by per-launch fill/drain, not by the matrix
+// cores.  Here a wave owns 32 rows (one MFMA M-tile) and carries them through every
+// layer: the layer input sits in a wave-private LDS tile, all weights of the stack sit
+// in LDS for the lifetime of the (persistent) workgroup, every accumulator tile goes
+// bias -> activation -> LDS (next layer's operand) and -> HBM once (saved for backward).
+// Waves never synchronise with each other after the weights are staged.
+//
+// Backward walks the layers in reverse with the same ownership: gZ = gY*act'(Y) in LDS,
+// dX = gZ W (next gY, written over the tile after the operand fragments are in
+// registers), dW += gZ^T X with the 32 rows as the contraction and the dW tiles living in
+// accumulator registers across ALL row tiles the wave processes; one partial per
+// workgroup goes to the workspace at the end and reduce.hip adds the partials up.
+//
+// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32).  A contraction chunk of C <= 32 indices is
+// issued as C/2 steps, lane half h taking indices base + (C/2)*h + t -- the same split
+// for both operands (C % 8 == 0 so a lane's values are whole 16-byte LDS reads).
+// Limits: every width <= 128 and a multiple of 8 (outputs: any n <= 128), <= 8 layers,
+// everything must fit LDS; otherwise CTR_ELIMIT and the caller uses the per-layer path.
+#include "ctr_common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kMaxLayers = 8;
+constexpr int kMaxDim = 128;
+
+struct LayerDesc {
+  const float* w;      // (n, k) row-major, ldw = k
+  const float* b;      // (n) or null
+  float* y;            // fwd: output (m, ldy); bwd: saved output (read)
+  int64_t ldy;
+  float* gw;           // bwd: (n, k) gradient accumulators (through the workspace)
+  float* gb;
+  int n, k, act;
+  int w_off;           // float offset of this layer's weights inside the LDS weight region
+  int acc_off;         // bwd: first dW accumulator tile of this layer
+};
+
+struct StackDesc {
+  LayerDesc l[kMaxLayers];
+  int nlayers;
+  int sa, sb;          // floats per row of the two wave-private LDS tiles (they swap roles per layer)
+  int wfloats;         // LDS floats used by all weights
+  int ntiles;          // bwd: dW accumulator tiles per wave
+};
+
+__device__ __forceinline__ int w_stride(int k) { return k + 4; }
+
+__device__ __forceinline__ void stage_weights(float* s_w, const StackDesc& d) {
+  for (int li = 0; li < d.nlayers; ++li) {
+    const LayerDesc& L = d.l[li];
+    float* dst = s_w + L.w_off;
+    const int ws = w_stride(L.k);
+    for (int i = threadIdx.x * 4; i < L.n * L.k; i += blockDim.x * 4) {
+      const int r = i / L.k, c = i - r * L.k;  // k % 4 == 0: a float4 never crosses a row
+      *reinterpret_cast<float4*>(dst + r * ws + c) = *reinterpret_cast<const float4*>(L.w + i);
+    }
+  }
+}
+
+// 16 (or fewer) contraction values of LDS row `row` for this lane: indices base + steps*h + t
+template <int STEPS>
+__device__ __forceinline__ void read_kc(const float* tile, int stride, int row, int base, int h, float (&f)[16]) {
+  const float4* q = reinterpret_cast<const float4*>(tile + row * stride + base + STEPS * h);
+#pragma unroll
+  for (int v = 0; v < STEPS / 4; ++v) {
+    const float4 x = q[v];
+    f[4 * v + 0] = x.x; f[4 * v + 1] = x.y; f[4 * v + 2] = x.z; f[4 * v + 3] = x.w;
+  }
+}
+
+// ------------------------------------------------------------------ forward
+// one contraction chunk of STEPS*2 indices for ONE 32-column tile (row j of the weights)
+template <int STEPS>
+__device__ __forceinline__ void fwd_chunk(const float* xt, int xstride, const float* wl, int wstride, int n, int j,
+                                          int base, int r, int h, floatx16& acc) {
+  float fa[16], fb[16];
+  read_kc<STEPS>(xt, xstride, r, base, h, fa);
+  if (j < n) {
+    read_kc<STEPS>(wl, wstride, j, base, h, fb);
+  } else {
+#pragma unroll
+    for (int t = 0; t < STEPS; ++t) fb[t] = 0.0f;
+  }
+#pragma unroll
+  for (int t = 0; t < STEPS; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc, 0, 0, 0);
+}
+
+__global__ void __launch_bounds__(kThreads)
+mlp_fwd_kernel(const StackDesc d, const float* __restrict__ x, int64_t ldx, int64_t m) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* s_w = lds;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // two wave-private tiles: layer l reads its input from one and writes its output to the
+  // other, so outputs never wait for the last operand read of the same tile
+  float* ta = lds + d.wfloats + wave * 32 * (d.sa + d.sb);
+  float* tb = ta + 32 * d.sa;
+  const int r = lane & 31, h = lane >> 5;
+  stage_weights(s_w, d);
+  __syncthreads();
+
+  const int64_t tiles = (m + 31) / 32;
+  const int k0 = d.l[0].k;
+  for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += (int64_t)gridDim.x * kWaves) {
+    const int64_t row0 = tile * 32;
+    // layer-0 input: 32 rows x k0 floats, coalesced dwordx4 loads -> LDS tile
+    for (int i = lane * 4; i < 32 * k0; i += 64 * 4) {
+      const int rr = i / k0, c = i - rr * k0;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + rr < m) v = *reinterpret_cast<const float4*>(x + (row0 + rr) * ldx + c);
+      *reinterpret_cast<float4*>(ta + rr * d.sa + c) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int li = 0; li < d.nlayers; ++li) {
+      const LayerDesc& L = d.l[li];
+      const float* wl = s_w + L.w_off;
+      const int ws = w_stride(L.k);
+      const int nct = (L.n + 31) / 32;
+      const float* xin = (li & 1) ? tb : ta;
+      float* xout = (li & 1) ? ta : tb;
+      const int sin = (li & 1) ? d.sb : d.sa, sout = (li & 1) ? d.sa : d.sb;
+      for (int ct = 0; ct < nct; ++ct) {
+        floatx16 a;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a[e] = 0.0f;
+        const int j = 32 * ct + r;
+        int base = 0;
+        for (; base + 32 <= L.k; base += 32) fwd_chunk<16>(xin, sin, wl, ws, L.n, j, base, r, h, a);
+        const int rem = L.k - base;  // 0, 8, 16 or 24
+        if (rem == 8) fwd_chunk<4>(xin, sin, wl, ws, L.n, j, base, r, h, a);
+        else if (rem == 16) fwd_chunk<8>(xin, sin, wl, ws, L.n, j, base, r, h, a);
+        else if (rem == 24) fwd_chunk<12>(xin, sin, wl, ws, L.n, j, base, r, h, a);
+        if (j < L.n) {
+          const float bias = L.b ? L.b[j] : 0.0f;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+            const float v = ctr_act(a[e] + bias, L.act);
+            xout[row * sout + j] = v;
+            if (row0 + row < m) L.y[(row0 + row) * L.ldy + j] = v;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// ------------------------------------------------------------------ backward
+// KS-mode fragment: values tile[(base + STEPS*h + t) * stride + col], t < STEPS
+template <int STEPS>
+__device__ __forceinline__ void read_ks(const float* tile, int stride, int col, int base, int h, float (&f)[16]) {
+#pragma unroll
+  for (int t = 0; t < STEPS; ++t) f[t] = tile[(base + STEPS * h + t) * stride + col];
+}
+
+// dX chunk for ONE 32-column tile: contraction over n, A = gZ rows (KC), B = W[n][col] (KS).
+// n need not be a multiple of 8: the gZ tile is zero-padded to the chunk width and weight
+// rows >= n read as zero.
+template <int STEPS>
+__device__ __forceinline__ void dx_chunk(const float* gt, int gstride, const float* wl, int wstride, int n, int k,
+                                         int col, int base, int r, int h, floatx16& acc) {
+  float fa[16], fb[16];
+  read_kc<STEPS>(gt, gstride, r, base, h, fa);
+  if (col < k) {
+#pragma unroll
+    for (int t = 0; t < STEPS; ++t) {
+      const int nn = base + STEPS * h + t;
+      fb[t] = nn < n ? wl[nn * wstride + col] : 0.0f;
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < STEPS; ++t) fb[t] = 0.0f;
+  }
+#pragma unroll
+  for (int t = 0; t < STEPS; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc, 0, 0, 0);
+}
+
+template <int MAXT>
+__global__ void __launch_bounds__(kThreads)
+mlp_bwd_kernel(const StackDesc d, const float* __restrict__ x, int64_t ldx, int64_t m, const float* __restrict__ gy,
+               int64_t ldgy, float* __restrict__ gx, int64_t ldgx, float* __restrict__ ws, int64_t slab) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* s_w = lds;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // two wave-private tiles P (stride sa) and Q (stride sb).  Walking the layers from the
+  // last one, the gradient tile and the layer-input tile swap every layer: dX_l is written
+  // over X_l (dW_l has consumed it) and is the gY of layer l-1, whose input then goes
+  // where gZ_l was.
+  float* tp = lds + d.wfloats + wave * 32 * (d.sa + d.sb);
+  float* tq = tp + 32 * d.sa;
+  const int r = lane & 31, h = lane >> 5;
+  stage_weights(s_w, d);
+  __syncthreads();
+
+  floatx16 dw[MAXT];  // dW accumulator tiles of every layer, alive across all row tiles
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dw[t][e] = 0.0f;
+  float db[kMaxLayers][2];  // lane j (and j+64) of layer li: bias-gradient partial
+#pragma unroll
+  for (int li = 0; li < kMaxLayers; ++li) db[li][0] = db[li][1] = 0.0f;
+
+  const int64_t tiles = (m + 31) / 32;
+  const int last = d.nlayers - 1;
+  for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += (int64_t)gridDim.x * kWaves) {
+    const int64_t row0 = tile * 32;
+    const int nl = d.l[last].n;
+    // gradient of the last layer's output -> P
+    for (int i = lane; i < 32 * nl; i += 64) {
+      const int rr = i / nl, c = i - rr * nl;
+      tp[rr * d.sa + c] = row0 + rr < m ? gy[(row0 + rr) * ldgy + c] : 0.0f;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int li = kMaxLayers - 1; li >= 0; --li) {
+      if (li <= last) {
+        const LayerDesc& L = d.l[li];
+        const bool even = ((last - li) & 1) == 0;
+        float* gt = even ? tp : tq;      // gY -> gZ of this layer
+        float* xt = even ? tq : tp;      // X_l, then dX_l
+        const int gs = even ? d.sa : d.sb, xs = even ? d.sb : d.sa;
+        // gZ = gY * act'(Y) in place (rows past m stay zero)
+        if (L.act != CTR_ACT_NONE) {
+          for (int i = lane; i < 32 * L.n; i += 64) {
+            const int rr = i / L.n, c = i - rr * L.n;
+            if (row0 + rr < m) gt[rr * gs + c] *= ctr_act_grad(L.y[(row0 + rr) * L.ldy + c], L.act);
+          }
+        }
+        {
+          // zero the columns [n, round_up(n, 8)) the last dX chunk will read
+          const int npad = (L.n + 7) / 8 * 8 - L.n;
+          for (int i = lane; i < 32 * npad; i += 64) {
+            const int rr = i / npad, c = i - rr * npad;
+            gt[rr * gs + L.n + c] = 0.0f;
+          }
+        }
+        // layer input X_l (layer 0: the stack input, else the saved output of layer l-1)
+        const float* src = li == 0 ? x : d.l[li > 0 ? li - 1 : 0].y;
+        const int64_t ld_in = li == 0 ? ldx : d.l[li > 0 ? li - 1 : 0].ldy;
+        for (int i = lane * 4; i < 32 * L.k; i += 64 * 4) {
+          const int rr = i / L.k, c = i - rr * L.k;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (row0 + rr < m) v = *reinterpret_cast<const float4*>(src + (row0 + rr) * ld_in + c);
+          *reinterpret_cast<float4*>(xt + rr * xs + c) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // bias gradient: lane j sums column j of gZ over the 32 rows
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int j = lane + 64 * half;
+          if (j < L.n) {
+            float t = 0.0f;
+            for (int rr = 0; rr < 32; ++rr) t += gt[rr * gs + j];
+            db[li][half] += t;
+          }
+        }
+        // dW_l[n][k] += sum_rows gZ[row][n] X[row][k]: contraction = the 32 rows, 16 steps.
+        // The accumulator index must be a compile-time constant (a run-time index would
+        // send the tiles to scratch), so walk every slot and take this layer's ones.
+        {
+          const int nrt = (L.n + 31) / 32, nkt = (L.k + 31) / 32;
+#pragma unroll
+          for (int s2 = 0; s2 < MAXT; ++s2) {
+            const int rel = s2 - L.acc_off;
+            if (rel >= 0 && rel < nrt * nkt) {
+              const int it = rel / nkt, jt = rel - it * nkt;
+              float fa[16], fb[16];
+              const int ncol = 32 * it + r, kcol = 32 * jt + r;
+              if (ncol < L.n) {
+                read_ks<16>(gt, gs, ncol, 0, h, fa);
+              } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) fa[t] = 0.0f;
+              }
+              if (kcol < L.k) {
+                read_ks<16>(xt, xs, kcol, 0, h, fb);
+              } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) fb[t] = 0.0f;
+              }
+#pragma unroll
+              for (int t = 0; t < 16; ++t) dw[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], dw[s2], 0, 0, 0);
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // dX_l = gZ W_l (32 x k): over X_l in LDS (the next layer's gY) or, for layer 0, to HBM
+        {
+          const float* wl = s_w + L.w_off;
+          const int wsd = w_stride(L.k);
+          const int nkt = (L.k + 31) / 32;
+          for (int ct = 0; ct < nkt; ++ct) {
+            floatx16 a;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a[e] = 0.0f;
+            const int col = 32 * ct + r;
+            int base = 0;
+            for (; base + 32 <= L.n; base += 32) dx_chunk<16>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a);
+            const int rem = L.n - base;  // 0..31, the tile is zero-padded to a multiple of 8
+            if (rem > 24) dx_chunk<16>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a);
+            else if (rem > 16) dx_chunk<12>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a);
+            else if (rem > 8) dx_chunk<8>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a);
+            else if (rem > 0) dx_chunk<4>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a);
+            if (col < L.k) {
+#pragma unroll
+              for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (li == 0) {
+                  if (gx && row0 + row < m) gx[(row0 + row) * ldgx + col] = a[e];
+                } else {
+                  xt[row * xs + col] = a[e];
+                }
+              }
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+  }
+
+  // workgroup partial of dW / db: the 4 waves add theirs in LDS, then one slab in the workspace
+  __syncthreads();
+  float* s_red = lds + d.wfloats;  // reuse the activation tiles: nothing reads them any more
+  // layout of a slab: for each layer  n*k weights then n biases, in layer order
+  int off = 0;
+  for (int li = 0; li < d.nlayers; ++li) {
+    const LayerDesc& L = d.l[li];
+    const int nkt = (L.k + 31) / 32, nrt = (L.n + 31) / 32;
+    const int cnt = L.n * L.k + L.n;
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) s_red[i] = 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int s2 = 0; s2 < MAXT; ++s2) {
+      const int rel = s2 - L.acc_off;
+      if (rel >= 0 && rel < nrt * nkt) {
+        const int it = rel / nkt, jt = rel - it * nkt;
+        const int kcol = 32 * jt + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int nrow = 32 * it + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (nrow < L.n && kcol < L.k) atomicAdd(s_red + nrow * L.k + kcol, dw[s2][e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int j = lane + 64 * half;
+#pragma unroll
+      for (int q = 0; q < kMaxLayers; ++q)
+        if (q == li && j < L.n) atomicAdd(s_red + L.n * L.k + j, db[q][half]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) ws[(int64_t)blockIdx.x * slab + off + i] = s_red[i];
+    __syncthreads();
+    off += cnt;
+  }
+}
+
+// ------------------------------------------------------------------ host
+struct Built {
+  StackDesc d;
+  size_t lds_bytes;
+  int64_t slab;
+};
+
+int build(const ctr_mlp_layer_t* layers, int nlayers, bool backward, Built* out) {
+  CTR_REQUIRE(layers && nlayers >= 1 && nlayers <= kMaxLayers, CTR_ELIMIT);
+  StackDesc& d = out->d;
+  d.nlayers = nlayers;
+  int woff = 0, maxk = 0, maxn = 0, tiles = 0;
+  int64_t slab = 0;
+  for (int i = 0; i < nlayers; ++i) {
+    const ctr_mlp_layer_t& s = layers[i];
+    CTR_REQUIRE(s.w && s.n >= 1 && s.k >= 8, CTR_EINVAL);
+    CTR_REQUIRE(s.n <= kMaxDim && s.k <= kMaxDim && s.k % 8 == 0, CTR_ELIMIT);
+    CTR_REQUIRE(i == 0 || (s.k == layers[i - 1].n), CTR_EINVAL);
+    CTR_REQUIRE(s.act >= CTR_ACT_NONE && s.act <= CTR_ACT_SIGMOID, CTR_EINVAL);
+    CTR_REQUIRE(s.y && s.ldy >= s.n && ctr_aligned16(s.w), CTR_EINVAL);
+    // intermediate outputs are re-read with dwordx4 as the next layer's input
+    CTR_REQUIRE(i == nlayers - 1 || (ctr_aligned16(s.y) && s.ldy % 4 == 0), CTR_EALIGN);
+    LayerDesc& L = d.l[i];
+    L.w = s.w; L.b = s.b; L.y = s.y; L.ldy = s.ldy; L.gw = s.gw; L.gb = s.gb;
+    L.n = s.n; L.k = s.k; L.act = s.act;
+    L.w_off = woff;
+    L.acc_off = tiles;
+    woff += s.n * (s.k + 4);
+    tiles += ((s.n + 31) / 32) * ((s.k + 31) / 32);
+    maxk = s.k > maxk ? s.k : maxk;
+    maxn = s.n > maxn ? s.n : maxn;
+    slab += (int64_t)s.n * s.k + s.n;
+    if (backward) CTR_REQUIRE(s.gw && s.gb, CTR_EINVAL);
+  }
+  d.wfloats = (woff + 3) / 4 * 4;
+  d.ntiles = tiles;
+  (void)maxk;
+  (void)maxn;
+  // widths the two swapping tiles must hold
+  int wa = 0, wb = 0;
+  if (backward) {
+    const int last = nlayers - 1;
+    for (int i = 0; i < nlayers; ++i) {
+      const bool even = ((last - i) & 1) == 0;  // gZ_i in P, X_i / dX_i in Q
+      int& wg = even ? wa : wb;
+      int& wx = even ? wb : wa;
+      const int n8 = (layers[i].n + 7) / 8 * 8;
+      wg = n8 > wg ? n8 : wg;
+      wx = layers[i].k > wx ? layers[i].k : wx;
+    }
+    int64_t biggest = 0;
+    for (int i = 0; i < nlayers; ++i) {
+      const int64_t c = (int64_t)layers[i].n * layers[i].k + layers[i].n;
+      biggest = c > biggest ? c : biggest;
+    }
+    d.sa = wa + 4;
+    d.sb = wb + 4;
+    const int64_t tiles_floats = (int64_t)kWaves * 32 * (d.sa + d.sb);
+    const int64_t act_region = tiles_floats > biggest ? tiles_floats : biggest;
+    out->lds_bytes = sizeof(float) * (d.wfloats + act_region);
+  } else {
+    for (int i = 0; i < nlayers; ++i) {
+      int& win = (i & 1) ? wb : wa;   // layer i reads tile A (even i) / B (odd i) ...
+      int& wout = (i & 1) ? wa : wb;  // ... and writes the other one
+      win = layers[i].k > win ? layers[i].k : win;
+      wout = layers[i].n > wout ? layers[i].n : wout;
+    }
+    d.sa = wa + 4;
+    d.sb = wb + 4;
+    out->lds_bytes = sizeof(float) * (d.wfloats + (int64_t)kWaves * 32 * (d.sa + d.sb));
+  }
+  out->slab = slab;
+  CTR_REQUIRE(out->lds_bytes <= 160 * 1024, CTR_ELIMIT);
+  return CTR_OK;
+}
+
+template <class K>
+int allow_lds(K kernel, size_t bytes) {
+  if (bytes <= 48 * 1024) return CTR_OK;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)bytes) == hipSuccess
+             ? CTR_OK
+             : CTR_ELAUNCH;
+}
+
+}  // namespace
+
+extern "C" int ctr_mlp_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
+                           void* stream) {
+  CTR_REQUIRE(m >= 0, CTR_EINVAL);
+  if (m == 0) return CTR_OK;
+  CTR_REQUIRE(x && ctr_aligned16(x) && ldx % 4 == 0, CTR_EALIGN);
+  Built b;
+  int rc = build(layers, nlayers, false, &b);
+  if (rc != CTR_OK) return rc;
+  CTR_REQUIRE(ldx >= b.d.l[0].k, CTR_EINVAL);
+  rc = allow_lds(mlp_fwd_kernel, b.lds_bytes);
+  if (rc != CTR_OK) return rc;
+  const int64_t tiles = ctr_ceil_div(m, 32);
+  int64_t grid = ctr_ceil_div(tiles, kWaves);
+  if (grid > 256) grid = 256;  // persistent: one workgroup per CU, weights staged once
+  hipLaunchKernelGGL(mlp_fwd_kernel, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, (hipStream_t)stream, b.d, x, ldx,
+                     m);
+  return ctr_launch_status();
+}
+
+extern "C" int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
+                           const float* gy, int64_t ldgy, float* gx, int64_t ldgx, float* workspace,
+                           int64_t workspace_floats, void* stream) {
+  CTR_REQUIRE(m >= 0, CTR_EINVAL);
+  if (m == 0) return CTR_OK;
+  CTR_REQUIRE(x && gy && workspace, CTR_EINVAL);
+  CTR_REQUIRE(ctr_aligned16(x) && ldx % 4 == 0, CTR_EALIGN);
+  Built b;
+  int rc = build(layers, nlayers, true, &b);
+  if (rc != CTR_OK) return rc;
+  CTR_REQUIRE(ldx >= b.d.l[0].k && ldgy >= b.d.l[nlayers - 1].n && (!gx || ldgx >= b.d.l[0].k), CTR_EINVAL);
+  CTR_REQUIRE(b.d.ntiles <= 16, CTR_ELIMIT);  // dW accumulators must fit the register file
+  const int64_t tiles = ctr_ceil_div(m, 32);
+  int64_t grid = ctr_ceil_div(tiles, kWaves);
+  if (grid > 256) grid = 256;
+  CTR_REQUIRE(workspace_floats >= grid * b.slab, CTR_ELIMIT);
+  hipStream_t st = (hipStream_t)stream;
+  rc = allow_lds(mlp_bwd_kernel<16>, b.lds_bytes);
+  if (rc != CTR_OK) return rc;
+  hipLaunchKernelGGL(mlp_bwd_kernel<16>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, st, b.d, x, ldx, m, gy, ldgy,
+                     gx, ldgx, workspace, b.slab);
+  rc = ctr_launch_status();
+  if (rc != CTR_OK) return rc;
+  CtrSegments segs;
+  segs.n = 0;
+  int64_t off = 0;
+  for (int i = 0; i < nlayers; ++i) {
+    const int64_t wn = (int64_t)layers[i].n * layers[i].k;
+    segs.s[segs.n++] = CtrSegment{off, wn, layers[i].gw};
+    segs.s[segs.n++] = CtrSegment{off + wn, layers[i].n, layers[i].gb};
+    off += wn + layers[i].n;
+  }
+  return ctr_reduce_segments(workspace, (int)grid, b.slab, segs, st);
+}

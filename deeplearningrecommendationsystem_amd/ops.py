@@ -291,8 +291,48 @@ def zero_grads(tensors: Sequence[torch.Tensor]) -> dict:
     return out
 
 
+FUSED_MLP = True  # narrow stacks run as one launch (ctr_mlp_fwd/bwd) when their shape allows
+_REFUSED = (-2, -4)  # CTR_ELIMIT / CTR_EALIGN: nothing was enqueued, take the per-layer path
+
+
+def _mlp_layer_array(layers, ys, grads=None):
+    arr = (_lib.MlpLayer * len(layers))()
+    for k, (layer, y) in enumerate(zip(layers, ys)):
+        e = arr[k]
+        e.w, e.b = layer.weight.data_ptr(), _lib.ptr(layer.bias)
+        e.y, e.ldy = y.data_ptr(), _ld(y)
+        e.n, e.k, e.act = layer.weight.shape[0], layer.weight.shape[1], layer.act
+        if grads is not None:
+            e.gw, e.gb = grads[k][0].data_ptr(), _lib.ptr(grads[k][1])
+    return arr
+
+
+def _fusable(x, layers) -> bool:
+    if not FUSED_MLP or len(layers) < 2 or len(layers) > 8:
+        return False
+    for layer in layers:
+        n, k = layer.weight.shape
+        if n > 128 or k > 128 or k % 8 or layer.bias is None or not layer.weight.is_contiguous():
+            return False
+    return x.shape[0] >= 1024
+
+
 def mlp_fwd(x: torch.Tensor, layers: Sequence[Layer], last_out: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
     """returns [x, y_1, ..., y_n]; the last layer may write into ``last_out``"""
+    x = _mat(x, "x")
+    m = x.shape[0]
+    if _fusable(x, layers):
+        ys = [torch.empty((m, layer.weight.shape[0]), dtype=torch.float32, device=x.device) for layer in layers[:-1]]
+        ys.append(last_out if last_out is not None else
+                  torch.empty((m, layers[-1].weight.shape[0]), dtype=torch.float32, device=x.device))
+        arr = _mlp_layer_array(layers, ys)
+        dims = [(layer.weight.shape[0], layer.weight.shape[1]) for layer in layers]
+        rc = _timed("mlp_fused_fwd", lambda: (4 * m * (dims[0][1] + sum(n for n, _ in dims)),
+                                              2 * m * sum(n * k for n, k in dims)),
+                    _lib.load().ctr_mlp_fwd, x.data_ptr(), _ld(x), m, arr, len(layers), _lib.stream_ptr())
+        if rc not in _REFUSED:
+            _lib.check(rc, "ctr_mlp_fwd")
+            return [x] + ys
     acts = [x]
     for k, layer in enumerate(layers):
         out = last_out if (k == len(layers) - 1) else None
@@ -305,6 +345,29 @@ def mlp_bwd(acts: Sequence[torch.Tensor], layers: Sequence[Layer], gy: torch.Ten
     """backward through ``mlp_fwd``; returns ([(gw, gb) per layer], gx of the
     first layer input or None)"""
     grads = [None] * len(layers)
+    if _fusable(acts[0], layers):
+        # whole stack in one launch: dX chain in LDS, dW tiles in registers
+        for k, layer in enumerate(layers):
+            if zeros is not None:
+                grads[k] = (zeros[id(layer.weight)], zeros[id(layer.bias)])
+            else:
+                grads[k] = (torch.zeros_like(layer.weight), torch.zeros_like(layer.bias))
+        x0 = _mat(acts[0], "x")
+        m = x0.shape[0]
+        gx = gx_first if want_gx_first else None
+        if want_gx_first and gx is None:
+            gx = torch.empty((m, x0.shape[1]), dtype=torch.float32, device=x0.device)
+        gy = _mat(gy, "gy")
+        arr = _mlp_layer_array(layers, acts[1:], grads)
+        ws = _scratch(x0.device)
+        dims = [(layer.weight.shape[0], layer.weight.shape[1]) for layer in layers]
+        rc = _timed("mlp_fused_bwd", lambda: (4 * m * (2 * dims[0][1] + 2 * sum(n for n, _ in dims)),
+                                              4 * m * sum(n * k for n, k in dims)),
+                    _lib.load().ctr_mlp_bwd, x0.data_ptr(), _ld(x0), m, arr, len(layers), gy.data_ptr(), _ld(gy),
+                    _lib.ptr(gx), _ld(gx) if gx is not None else 0, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        if rc not in _REFUSED:
+            _lib.check(rc, "ctr_mlp_bwd")
+            return grads, gx
     g = gy
     for k in range(len(layers) - 1, -1, -1):
         layer = layers[k]

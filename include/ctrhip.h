@@ -235,6 +235,35 @@ int ctr_gru_bwd(const float* gi, int64_t ldgi, const float* w_hh, const float* b
                 int64_t batch, int len, int dim, const float* glast, int64_t ldgl, float* dgi, float* dgh,
                 void* stream);
 
+/* ------------------------------------------------------------------------
+ * A whole stack of narrow nn.Linear(+activation) layers in one launch (forward) and
+ * one launch (backward): e.g. NeuralCF's tower, model/neuralcf.py:48-51.  A wave
+ * carries 32 rows through every layer with the activations in LDS and all weights
+ * of the stack resident in LDS.  Limits: <= 8 layers, every k a multiple of 8 and
+ * <= 128, every n <= 128, k[i] == n[i-1], weights 16-byte aligned, intermediate
+ * outputs 16-byte aligned with ldy % 4 == 0.  Anything else returns CTR_ELIMIT /
+ * CTR_EALIGN without enqueueing; use ctr_linear_* layer by layer then.
+ * ---------------------------------------------------------------------- */
+typedef struct ctr_mlp_layer {
+  const float* w;   /* (n, k) row-major */
+  const float* b;   /* (n) or NULL */
+  float* y;         /* forward: output (m, ldy), kept for backward; backward: read */
+  int64_t ldy;
+  float* gw;        /* backward: (n, k), accumulated into (+=) */
+  float* gb;        /* backward: (n),   accumulated into (+=) */
+  int32_t n, k, act;
+  int32_t reserved;
+} ctr_mlp_layer_t;
+
+/* y_0 = act_0(x W_0^T + b_0), y_i = act_i(y_{i-1} W_i^T + b_i); layers: host array */
+int ctr_mlp_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
+                void* stream);
+/* gy: gradient of the LAST layer's output; gx (nullable): gradient of x.  workspace is
+ * required: (number of workgroups <= 256) * sum_i (n_i*k_i + n_i) floats. */
+int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
+                const float* gy, int64_t ldgy, float* gx, int64_t ldgx,
+                float* workspace, int64_t workspace_floats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,8 @@ def test_code_object_targets_gfx950_only(lib):
 def test_field_struct_matches_header_size(lib):
     # 6 int32 + 2 int64 + 6 pointers + 1 int64 = 96 bytes, as ctr_field_t
     assert ctypes.sizeof(lib.Field) == 96
+    # 3 pointers + int64 + 2 pointers + 4 int32 = 64 bytes, as ctr_mlp_layer_t
+    assert ctypes.sizeof(lib.MlpLayer) == 64
 
 
 def test_strerror(lib):
@@ -96,6 +98,8 @@ def _parse_header_prototypes():
                 a = a.strip()
                 if "ctr_field_t" in a:
                     kinds.append("field*")
+                elif "ctr_mlp_layer_t" in a:
+                    kinds.append("mlp*")
                 elif "int32_t*" in a.replace(" *", "*") and "const" in a:
                     kinds.append("i32*")
                 elif "*" in a:
@@ -123,6 +127,8 @@ def test_ctypes_signatures_match_header_prototypes(lib):
                 got.append(to_kind[a])
             elif a is ctypes.POINTER(lib.Field):
                 got.append("field*")
+            elif a is ctypes.POINTER(lib.MlpLayer):
+                got.append("mlp*")
             elif a is ctypes.POINTER(ctypes.c_int32):
                 got.append("i32*")
             else:

@@ -342,3 +342,70 @@ def test_gru_recurrence(ops, dim, length, batch):
     torch.testing.assert_close(g_w_hh.cpu(), leaves[1].grad.float(), **tol)
     torch.testing.assert_close(g_b_ih.cpu(), leaves[2].grad.float(), **tol)
     torch.testing.assert_close(g_b_hh.cpu(), leaves[3].grad.float(), **tol)
+
+
+def _close_except_relu_flips(got, want, rtol, atol, max_bad=2e-4):
+    """a ReLU unit whose pre-activation is within rounding of 0 can be on in fp32 and off
+    in fp64 (or the reverse): its row's gradient then legitimately differs.  Allow a
+    vanishing fraction of such elements, require everything else to agree."""
+    bad = ~torch.isclose(got, want, rtol=rtol, atol=atol)
+    frac = bad.float().mean().item()
+    assert frac <= max_bad, f"{bad.sum().item()} of {bad.numel()} elements differ ({frac:.2e})"
+
+
+FUSED_STACKS = [
+    # (m, dims, activations)  dims[0] = input width
+    (65536, [128, 64, 32, 16, 8, 64], [1, 1, 1, 1, 0]),     # NeuralCF tower at BASELINE configs[1]
+    (1500, [64, 128, 8, 40, 1], [1, 0, 2, 2]),               # odd batch, sigmoid, n = 1 head, n not % 8
+    (1024, [8, 8], [1]),                                     # single layer is refused (falls back): still right
+    (4097, [24, 56, 104, 16], [1, 1, 1]),                    # 24-wide remainder chunks
+]
+
+
+@pytest.mark.parametrize("m,dims,acts_", FUSED_STACKS)
+def test_fused_mlp_matches_layerwise_and_fp64(ops, m, dims, acts_):
+    g = torch.Generator().manual_seed(m + len(dims))
+    x = torch.randn(m, dims[0] + 8, generator=g)[:, 4:4 + dims[0]]      # column slice: ld != k
+    ws = [torch.randn(n, k, generator=g) / k ** 0.5 for k, n in zip(dims[:-1], dims[1:])]
+    bs = [torch.randn(n, generator=g) for n in dims[1:]]
+    gy = torch.randn(m, dims[-1], generator=g)
+
+    def run(fused):
+        ops.FUSED_MLP = fused
+        big = torch.zeros(m, dims[0] + 8, device=DEV)
+        big[:, 4:4 + dims[0]] = x.to(DEV)
+        layers = [ops.Layer(w.to(DEV), b.to(DEV), a) for w, b, a in zip(ws, bs, acts_)]
+        acts = ops.mlp_fwd(big[:, 4:4 + dims[0]], layers)
+        grads, gx = ops.mlp_bwd(acts, layers, gy.to(DEV), None)
+        return acts, grads, gx
+    try:
+        acts_f, grads_f, gx_f = run(True)
+        acts_l, grads_l, gx_l = run(False)
+    finally:
+        ops.FUSED_MLP = True
+
+    # fp64 forward reference
+    h = x.double()
+    for w, b, a in zip(ws, bs, acts_):
+        z = h @ w.double().T + b.double()
+        h = [z, torch.relu(z), torch.sigmoid(z)][a]
+    torch.testing.assert_close(acts_f[-1].cpu(), h.float(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(acts_f[-1], acts_l[-1], rtol=1e-5, atol=1e-5)
+
+    # fp64 backward reference through the activations the kernel saved: a ReLU unit whose
+    # pre-activation is within rounding of 0 may be on in fp32 and off in fp64, which would
+    # change a whole row of dW -- the derivative is taken where the forward actually went
+    saved = [a.cpu().double() for a in acts_f]
+    gcur = gy.double()
+    ref = []
+    for k in range(len(ws) - 1, -1, -1):
+        y = saved[k + 1]
+        gz = gcur * [torch.ones_like(y), (y > 0).double(), y * (1 - y)][acts_[k]]
+        ref.append((gz.T @ saved[k], gz.sum(0)))
+        gcur = gz @ ws[k].double()
+    ref.reverse()
+    scale = max(1.0, m ** 0.5)
+    torch.testing.assert_close(gx_f.cpu(), gcur.float(), rtol=1e-4, atol=1e-5)
+    for (gw, gb), (rw, rb) in zip(grads_f, ref):
+        torch.testing.assert_close(gw.cpu(), rw.float(), rtol=1e-4, atol=1e-5 * scale)
+        torch.testing.assert_close(gb.cpu(), rb.float(), rtol=1e-4, atol=1e-5 * scale)
