@@ -39,7 +39,10 @@ struct LayerDesc {
   float* gw;           // bwd: (n, k) gradient accumulators (through the workspace)
   float* gb;
   int n, k, act;
+  CtrFastDiv div_n;    // / n        (element loops over a [32][n] tile)
+  CtrFastDiv div_k4;   // / (k / 4)  (dwordx4 loops over a [32][k] tile)
   int w_off;           // float offset of this layer's weights inside the LDS weight region
+  int b_off;           // fwd: float offset of this layer's bias inside the LDS weight region
   int acc_off;         // bwd: first dW accumulator tile of this layer
 };
 
@@ -47,15 +50,19 @@ struct StackDesc {
   LayerDesc l[kMaxLayers];
   int nlayers;
   int sa, sb;          // floats per row of the two wave-private LDS tiles (they swap roles per layer)
-  int wfloats;         // LDS floats used by all weights
+  int wfloats;         // LDS floats used by all weights (+ biases, forward)
   int ntiles;          // bwd: dW accumulator tiles per wave
+  int nsum;            // bwd: sum of n over the layers (per-wave bias-gradient slots in LDS)
+  int db_off[kMaxLayers];  // bwd: first bias-gradient slot of each layer
 };
 
 __device__ __forceinline__ int w_stride(int k) { return k + 4; }
 
-__device__ __forceinline__ void stage_weights(float* s_w, const StackDesc& d) {
+__device__ __forceinline__ void stage_weights(float* s_w, const StackDesc& d, bool with_bias) {
   for (int li = 0; li < d.nlayers; ++li) {
-    const LayerDesc& L = d.l[li];
+    const LayerDesc L = d.l[li];  // by value: registers, not an LDS reload after every LDS store
+    if (with_bias)
+      for (int i = threadIdx.x; i < L.n; i += blockDim.x) s_w[L.b_off + i] = L.b ? L.b[i] : 0.0f;
     float* dst = s_w + L.w_off;
     const int ws = w_stride(L.k);
     for (int i = threadIdx.x * 4; i < L.n * L.k; i += blockDim.x * 4) {
@@ -76,11 +83,95 @@ __device__ __forceinline__ void read_kc(const float* tile, int stride, int row, 
   }
 }
 
+// ---- tile movers: every lane issues U independent global loads before the first LDS write
+// (a wave is alone on its SIMD, so a load-then-use loop would pay the full HBM latency
+// once per iteration) ----
+
+// [32][width] fp32 tile, width % 4 == 0, 16-byte aligned rows: src rows row0.. (zero past m)
+template <int U>
+__device__ __forceinline__ void tile_load4(float* tile, int stride, const float* __restrict__ src, int64_t ld,
+                                           int64_t row0, int64_t m, int width, const CtrFastDiv& div_w4, int lane) {
+  const int units = 8 * width;  // dwordx4 units in the tile
+  for (int i0 = lane; i0 < units; i0 += 64 * U) {
+    float4 v[U];
+    int off[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + 64 * u;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      off[u] = -1;
+      if (i < units) {
+        const int rr = (int)ctr_div((uint32_t)i, div_w4), c = (i - rr * (width / 4)) * 4;
+        off[u] = rr * stride + c;
+        if (row0 + rr < m) v[u] = *reinterpret_cast<const float4*>(src + (row0 + rr) * ld + c);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (off[u] >= 0) *reinterpret_cast<float4*>(tile + off[u]) = v[u];
+  }
+}
+
+// same for arbitrary width / alignment, one float per lane and load
+template <int U>
+__device__ __forceinline__ void tile_load1(float* tile, int stride, const float* __restrict__ src, int64_t ld,
+                                           int64_t row0, int64_t m, int width, const CtrFastDiv& div_w, int lane) {
+  const int units = 32 * width;
+  for (int i0 = lane; i0 < units; i0 += 64 * U) {
+    float v[U];
+    int off[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + 64 * u;
+      v[u] = 0.0f;
+      off[u] = -1;
+      if (i < units) {
+        const int rr = (int)ctr_div((uint32_t)i, div_w), c = i - rr * width;
+        off[u] = rr * stride + c;
+        if (row0 + rr < m) v[u] = src[(row0 + rr) * ld + c];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (off[u] >= 0) tile[off[u]] = v[u];
+  }
+}
+
+// tile[r][c] *= act'(y[row0+r][c]) for a [32][width] tile (rows past m are zero already)
+template <int U>
+__device__ __forceinline__ void tile_mask(float* tile, int stride, const float* __restrict__ y, int64_t ld,
+                                          int64_t row0, int64_t m, int width, const CtrFastDiv& div_w, int act,
+                                          int lane) {
+  const int units = 32 * width;
+  for (int i0 = lane; i0 < units; i0 += 64 * U) {
+    float v[U];
+    int off[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + 64 * u;
+      v[u] = 0.0f;
+      off[u] = -1;
+      if (i < units) {
+        const int rr = (int)ctr_div((uint32_t)i, div_w), c = i - rr * width;
+        if (row0 + rr < m) {
+          off[u] = rr * stride + c;
+          v[u] = y[(row0 + rr) * ld + c];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (off[u] >= 0) tile[off[u]] *= ctr_act_grad(v[u], act);
+  }
+}
+
 // ------------------------------------------------------------------ forward
 // one contraction chunk of STEPS*2 indices for ONE 32-column tile (row j of the weights)
+// (two accumulator chains, even / odd steps: a dependent chain of this MFMA runs at ~0.4x
+// its issue rate and a wave is alone on its SIMD here)
 template <int STEPS>
 __device__ __forceinline__ void fwd_chunk(const float* xt, int xstride, const float* wl, int wstride, int n, int j,
-                                          int base, int r, int h, floatx16& acc) {
+                                          int base, int r, int h, floatx16& acc0, floatx16& acc1) {
   float fa[16], fb[16];
   read_kc<STEPS>(xt, xstride, r, base, h, fa);
   if (j < n) {
@@ -90,61 +181,95 @@ __device__ __forceinline__ void fwd_chunk(const float* xt, int xstride, const fl
     for (int t = 0; t < STEPS; ++t) fb[t] = 0.0f;
   }
 #pragma unroll
-  for (int t = 0; t < STEPS; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc, 0, 0, 0);
+  for (int t = 0; t < STEPS; t += 2) {
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t + 1], fb[t + 1], acc1, 0, 0, 0);
+  }
 }
 
 __global__ void __launch_bounds__(kThreads)
-mlp_fwd_kernel(const StackDesc d, const float* __restrict__ x, int64_t ldx, int64_t m) {
+mlp_fwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int64_t m) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  // layer descriptors are read inside the per-tile layer loop: from LDS, not from the
+  // kernarg segment (320 scalar loads + waits per wave otherwise, ~40 % of the run time)
+  __shared__ StackDesc s_desc;
+  for (int i = threadIdx.x; i < (int)(sizeof(StackDesc) / 4); i += blockDim.x)
+    reinterpret_cast<uint32_t*>(&s_desc)[i] = reinterpret_cast<const uint32_t*>(&dk)[i];
+  __syncthreads();
+  const StackDesc& d = s_desc;
   float* s_w = lds;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // two wave-private tiles: layer l reads its input from one and writes its output to the
   // other, so outputs never wait for the last operand read of the same tile
-  float* ta = lds + d.wfloats + wave * 32 * (d.sa + d.sb);
-  float* tb = ta + 32 * d.sa;
+  const int sa = d.sa, sb = d.sb, nlayers = d.nlayers;
+  float* ta = lds + d.wfloats + wave * 32 * (sa + sb);
+  float* tb = ta + 32 * sa;
   const int r = lane & 31, h = lane >> 5;
-  stage_weights(s_w, d);
+  stage_weights(s_w, d, true);
   __syncthreads();
 
   const int64_t tiles = (m + 31) / 32;
   const int k0 = d.l[0].k;
-  for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += (int64_t)gridDim.x * kWaves) {
-    const int64_t row0 = tile * 32;
-    // layer-0 input: 32 rows x k0 floats, coalesced dwordx4 loads -> LDS tile
-    for (int i = lane * 4; i < 32 * k0; i += 64 * 4) {
-      const int rr = i / k0, c = i - rr * k0;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 + rr < m) v = *reinterpret_cast<const float4*>(x + (row0 + rr) * ldx + c);
-      *reinterpret_cast<float4*>(ta + rr * d.sa + c) = v;
+  // layer-0 input rows of a tile as dwordx4 units held in registers (k0 <= 128: <= 16 per
+  // lane): the NEXT tile's rows are in flight while the current tile goes through the stack
+  float4 pre[16];
+  const int units = 8 * k0;
+  const CtrFastDiv div0 = d.l[0].div_k4;
+  auto fetch = [&](int64_t tl) {
+    const int64_t r0 = tl * 32;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = lane + 64 * u;
+      pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < units && tl < tiles) {
+        const int rr = (int)ctr_div((uint32_t)i, div0), c = (i - rr * (k0 / 4)) * 4;
+        if (r0 + rr < m) pre[u] = *reinterpret_cast<const float4*>(x + (r0 + rr) * ldx + c);
+      }
     }
+  };
+  const int64_t tstride = (int64_t)gridDim.x * kWaves;
+  fetch((int64_t)blockIdx.x * kWaves + wave);
+  for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += tstride) {
+    const int64_t row0 = tile * 32;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int i = lane + 64 * u;
+      if (i < units) {
+        const int rr = (int)ctr_div((uint32_t)i, div0), c = (i - rr * (k0 / 4)) * 4;
+        *reinterpret_cast<float4*>(ta + rr * sa + c) = pre[u];
+      }
+    }
+    fetch(tile + tstride);
     __builtin_amdgcn_wave_barrier();
-    for (int li = 0; li < d.nlayers; ++li) {
-      const LayerDesc& L = d.l[li];
+    for (int li = 0; li < nlayers; ++li) {
+      const LayerDesc L = d.l[li];  // by value: registers, not an LDS reload after every LDS store
       const float* wl = s_w + L.w_off;
       const int ws = w_stride(L.k);
       const int nct = (L.n + 31) / 32;
       const float* xin = (li & 1) ? tb : ta;
       float* xout = (li & 1) ? ta : tb;
-      const int sin = (li & 1) ? d.sb : d.sa, sout = (li & 1) ? d.sa : d.sb;
+      const int sin = (li & 1) ? sb : sa, sout = (li & 1) ? sa : sb;
       for (int ct = 0; ct < nct; ++ct) {
-        floatx16 a;
+        floatx16 a, a1;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) a[e] = 0.0f;
+        for (int e = 0; e < 16; ++e) a[e] = a1[e] = 0.0f;
         const int j = 32 * ct + r;
         int base = 0;
-        for (; base + 32 <= L.k; base += 32) fwd_chunk<16>(xin, sin, wl, ws, L.n, j, base, r, h, a);
+        for (; base + 32 <= L.k; base += 32) fwd_chunk<16>(xin, sin, wl, ws, L.n, j, base, r, h, a, a1);
         const int rem = L.k - base;  // 0, 8, 16 or 24
-        if (rem == 8) fwd_chunk<4>(xin, sin, wl, ws, L.n, j, base, r, h, a);
-        else if (rem == 16) fwd_chunk<8>(xin, sin, wl, ws, L.n, j, base, r, h, a);
-        else if (rem == 24) fwd_chunk<12>(xin, sin, wl, ws, L.n, j, base, r, h, a);
+        if (rem == 8) fwd_chunk<4>(xin, sin, wl, ws, L.n, j, base, r, h, a, a1);
+        else if (rem == 16) fwd_chunk<8>(xin, sin, wl, ws, L.n, j, base, r, h, a, a1);
+        else if (rem == 24) fwd_chunk<12>(xin, sin, wl, ws, L.n, j, base, r, h, a, a1);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a[e] += a1[e];
         if (j < L.n) {
-          const float bias = L.b ? L.b[j] : 0.0f;
+          const float bias = s_w[L.b_off + j];
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
             const float v = ctr_act(a[e] + bias, L.act);
             xout[row * sout + j] = v;
-            if (row0 + row < m) L.y[(row0 + row) * L.ldy + j] = v;
+            if (row0 + row < m) ctr_stg(L.y + (row0 + row) * L.ldy + j, v);
           }
         }
       }
@@ -166,7 +291,7 @@ __device__ __forceinline__ void read_ks(const float* tile, int stride, int col, 
 // rows >= n read as zero.
 template <int STEPS>
 __device__ __forceinline__ void dx_chunk(const float* gt, int gstride, const float* wl, int wstride, int n, int k,
-                                         int col, int base, int r, int h, floatx16& acc) {
+                                         int col, int base, int r, int h, floatx16& acc0, floatx16& acc1) {
   float fa[16], fb[16];
   read_kc<STEPS>(gt, gstride, r, base, h, fa);
   if (col < k) {
@@ -180,24 +305,33 @@ __device__ __forceinline__ void dx_chunk(const float* gt, int gstride, const flo
     for (int t = 0; t < STEPS; ++t) fb[t] = 0.0f;
   }
 #pragma unroll
-  for (int t = 0; t < STEPS; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc, 0, 0, 0);
+  for (int t = 0; t < STEPS; t += 2) {
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t + 1], fb[t + 1], acc1, 0, 0, 0);
+  }
 }
 
 template <int MAXT>
 __global__ void __launch_bounds__(kThreads)
-mlp_bwd_kernel(const StackDesc d, const float* __restrict__ x, int64_t ldx, int64_t m, const float* __restrict__ gy,
+mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int64_t m, const float* __restrict__ gy,
                int64_t ldgy, float* __restrict__ gx, int64_t ldgx, float* __restrict__ ws, int64_t slab) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ StackDesc s_desc;  // see mlp_fwd_kernel
+  for (int i = threadIdx.x; i < (int)(sizeof(StackDesc) / 4); i += blockDim.x)
+    reinterpret_cast<uint32_t*>(&s_desc)[i] = reinterpret_cast<const uint32_t*>(&dk)[i];
+  __syncthreads();
+  const StackDesc& d = s_desc;
   float* s_w = lds;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // two wave-private tiles P (stride sa) and Q (stride sb).  Walking the layers from the
   // last one, the gradient tile and the layer-input tile swap every layer: dX_l is written
   // over X_l (dW_l has consumed it) and is the gY of layer l-1, whose input then goes
   // where gZ_l was.
-  float* tp = lds + d.wfloats + wave * 32 * (d.sa + d.sb);
-  float* tq = tp + 32 * d.sa;
+  const int sa = d.sa, sb = d.sb;
+  float* tp = lds + d.wfloats + wave * 32 * (sa + sb);
+  float* tq = tp + 32 * sa;
   const int r = lane & 31, h = lane >> 5;
-  stage_weights(s_w, d);
+  stage_weights(s_w, d, false);
   __syncthreads();
 
   floatx16 dw[MAXT];  // dW accumulator tiles of every layer, alive across all row tiles
@@ -205,36 +339,29 @@ mlp_bwd_kernel(const StackDesc d, const float* __restrict__ x, int64_t ldx, int6
   for (int t = 0; t < MAXT; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) dw[t][e] = 0.0f;
-  float db[kMaxLayers][2];  // lane j (and j+64) of layer li: bias-gradient partial
-#pragma unroll
-  for (int li = 0; li < kMaxLayers; ++li) db[li][0] = db[li][1] = 0.0f;
+  // bias-gradient partials: nsum floats per wave in LDS (lane j owns column j of each layer)
+  float* s_db = lds + d.wfloats + kWaves * 32 * (sa + sb) + wave * d.nsum;
+  for (int i = lane; i < d.nsum; i += 64) s_db[i] = 0.0f;
 
   const int64_t tiles = (m + 31) / 32;
   const int last = d.nlayers - 1;
+  const CtrFastDiv div_last = d.l[last].div_n;
+  const int nl = d.l[last].n;
   for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += (int64_t)gridDim.x * kWaves) {
     const int64_t row0 = tile * 32;
-    const int nl = d.l[last].n;
     // gradient of the last layer's output -> P
-    for (int i = lane; i < 32 * nl; i += 64) {
-      const int rr = i / nl, c = i - rr * nl;
-      tp[rr * d.sa + c] = row0 + rr < m ? gy[(row0 + rr) * ldgy + c] : 0.0f;
-    }
+    tile_load1<8>(tp, sa, gy, ldgy, row0, m, nl, div_last, lane);
     __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int li = kMaxLayers - 1; li >= 0; --li) {
-      if (li <= last) {
-        const LayerDesc& L = d.l[li];
+    for (int li = last; li >= 0; --li) {
+      {
+        const LayerDesc L = d.l[li];  // by value: registers, not an LDS reload after every LDS store
+        const int dboff = d.db_off[li];
         const bool even = ((last - li) & 1) == 0;
         float* gt = even ? tp : tq;      // gY -> gZ of this layer
         float* xt = even ? tq : tp;      // X_l, then dX_l
-        const int gs = even ? d.sa : d.sb, xs = even ? d.sb : d.sa;
+        const int gs = even ? sa : sb, xs = even ? sb : sa;
         // gZ = gY * act'(Y) in place (rows past m stay zero)
-        if (L.act != CTR_ACT_NONE) {
-          for (int i = lane; i < 32 * L.n; i += 64) {
-            const int rr = i / L.n, c = i - rr * L.n;
-            if (row0 + rr < m) gt[rr * gs + c] *= ctr_act_grad(L.y[(row0 + rr) * L.ldy + c], L.act);
-          }
-        }
+        if (L.act != CTR_ACT_NONE) tile_mask<8>(gt, gs, L.y, L.ldy, row0, m, L.n, L.div_n, L.act, lane);
         {
           // zero the columns [n, round_up(n, 8)) the last dX chunk will read
           const int npad = (L.n + 7) / 8 * 8 - L.n;
@@ -244,14 +371,13 @@ mlp_bwd_kernel(const StackDesc d, const float* __restrict__ x, int64_t ldx, int6
           }
         }
         // layer input X_l (layer 0: the stack input, else the saved output of layer l-1)
-        const float* src = li == 0 ? x : d.l[li > 0 ? li - 1 : 0].y;
-        const int64_t ld_in = li == 0 ? ldx : d.l[li > 0 ? li - 1 : 0].ldy;
-        for (int i = lane * 4; i < 32 * L.k; i += 64 * 4) {
-          const int rr = i / L.k, c = i - rr * L.k;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (row0 + rr < m) v = *reinterpret_cast<const float4*>(src + (row0 + rr) * ld_in + c);
-          *reinterpret_cast<float4*>(xt + rr * xs + c) = v;
+        const float* src = x;
+        int64_t ld_in = ldx;
+        if (li > 0) {
+          src = d.l[li > 0 ? li - 1 : 0].y;
+          ld_in = d.l[li > 0 ? li - 1 : 0].ldy;
         }
+        tile_load4<4>(xt, xs, src, ld_in, row0, m, L.k, L.div_k4, lane);
         __builtin_amdgcn_wave_barrier();
         // bias gradient: lane j sums column j of gZ over the 32 rows
 #pragma unroll
@@ -260,7 +386,7 @@ mlp_bwd_kernel(const StackDesc d, const float* __restrict__ x, int64_t ldx, int6
           if (j < L.n) {
             float t = 0.0f;
             for (int rr = 0; rr < 32; ++rr) t += gt[rr * gs + j];
-            db[li][half] += t;
+            s_db[dboff + j] += t;
           }
         }
         // dW_l[n][k] += sum_rows gZ[row][n] X[row][k]: contraction = the 32 rows, 16 steps.
@@ -269,26 +395,46 @@ mlp_bwd_kernel(const StackDesc d, const float* __restrict__ x, int64_t ldx, int6
         {
           const int nrt = (L.n + 31) / 32, nkt = (L.k + 31) / 32;
 #pragma unroll
-          for (int s2 = 0; s2 < MAXT; ++s2) {
-            const int rel = s2 - L.acc_off;
-            if (rel >= 0 && rel < nrt * nkt) {
-              const int it = rel / nkt, jt = rel - it * nkt;
-              float fa[16], fb[16];
-              const int ncol = 32 * it + r, kcol = 32 * jt + r;
-              if (ncol < L.n) {
-                read_ks<16>(gt, gs, ncol, 0, h, fa);
-              } else {
+          for (int s2 = 0; s2 < MAXT; s2 += 2) {
+            // two slots at a time, their MFMAs interleaved: independent accumulators back
+            // to back instead of one 16-deep dependent chain
+            const int relA = s2 - L.acc_off, relB = relA + 1;
+            const bool okA = relA >= 0 && relA < nrt * nkt, okB = relB >= 0 && relB < nrt * nkt;
+            if (okA || okB) {
+              float faA[16], fbA[16], faB[16], fbB[16];
+              {
+                const int it = okA ? relA / nkt : 0, jt = okA ? relA - it * nkt : 0;
+                const int ncol = 32 * it + r, kcol = 32 * jt + r;
+                if (okA && ncol < L.n) read_ks<16>(gt, gs, ncol, 0, h, faA);
+                else {
 #pragma unroll
-                for (int t = 0; t < 16; ++t) fa[t] = 0.0f;
+                  for (int t = 0; t < 16; ++t) faA[t] = 0.0f;
+                }
+                if (okA && kcol < L.k) read_ks<16>(xt, xs, kcol, 0, h, fbA);
+                else {
+#pragma unroll
+                  for (int t = 0; t < 16; ++t) fbA[t] = 0.0f;
+                }
               }
-              if (kcol < L.k) {
-                read_ks<16>(xt, xs, kcol, 0, h, fb);
-              } else {
+              {
+                const int it = okB ? relB / nkt : 0, jt = okB ? relB - it * nkt : 0;
+                const int ncol = 32 * it + r, kcol = 32 * jt + r;
+                if (okB && ncol < L.n) read_ks<16>(gt, gs, ncol, 0, h, faB);
+                else {
 #pragma unroll
-                for (int t = 0; t < 16; ++t) fb[t] = 0.0f;
+                  for (int t = 0; t < 16; ++t) faB[t] = 0.0f;
+                }
+                if (okB && kcol < L.k) read_ks<16>(xt, xs, kcol, 0, h, fbB);
+                else {
+#pragma unroll
+                  for (int t = 0; t < 16; ++t) fbB[t] = 0.0f;
+                }
               }
 #pragma unroll
-              for (int t = 0; t < 16; ++t) dw[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], dw[s2], 0, 0, 0);
+              for (int t = 0; t < 16; ++t) {
+                dw[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(faA[t], fbA[t], dw[s2], 0, 0, 0);
+                dw[s2 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(faB[t], fbB[t], dw[s2 + 1], 0, 0, 0);
+              }
             }
           }
         }
@@ -299,23 +445,25 @@ mlp_bwd_kernel(const StackDesc d, const float* __restrict__ x, int64_t ldx, int6
           const int wsd = w_stride(L.k);
           const int nkt = (L.k + 31) / 32;
           for (int ct = 0; ct < nkt; ++ct) {
-            floatx16 a;
+            floatx16 a, a1;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) a[e] = 0.0f;
+            for (int e = 0; e < 16; ++e) a[e] = a1[e] = 0.0f;
             const int col = 32 * ct + r;
             int base = 0;
-            for (; base + 32 <= L.n; base += 32) dx_chunk<16>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a);
+            for (; base + 32 <= L.n; base += 32) dx_chunk<16>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a, a1);
             const int rem = L.n - base;  // 0..31, the tile is zero-padded to a multiple of 8
-            if (rem > 24) dx_chunk<16>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a);
-            else if (rem > 16) dx_chunk<12>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a);
-            else if (rem > 8) dx_chunk<8>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a);
-            else if (rem > 0) dx_chunk<4>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a);
+            if (rem > 24) dx_chunk<16>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a, a1);
+            else if (rem > 16) dx_chunk<12>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a, a1);
+            else if (rem > 8) dx_chunk<8>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a, a1);
+            else if (rem > 0) dx_chunk<4>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a, a1);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a[e] += a1[e];
             if (col < L.k) {
 #pragma unroll
               for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (li == 0) {
-                  if (gx && row0 + row < m) gx[(row0 + row) * ldgx + col] = a[e];
+                  if (gx && row0 + row < m) ctr_stg(gx + (row0 + row) * ldgx + col, a[e]);
                 } else {
                   xt[row * xs + col] = a[e];
                 }
@@ -331,10 +479,11 @@ mlp_bwd_kernel(const StackDesc d, const float* __restrict__ x, int64_t ldx, int6
   // workgroup partial of dW / db: the 4 waves add theirs in LDS, then one slab in the workspace
   __syncthreads();
   float* s_red = lds + d.wfloats;  // reuse the activation tiles: nothing reads them any more
+  const float* s_dbv = lds + d.wfloats + kWaves * 32 * (sa + sb);  // the waves' bias partials, kept beyond the tiles
   // layout of a slab: for each layer  n*k weights then n biases, in layer order
   int off = 0;
   for (int li = 0; li < d.nlayers; ++li) {
-    const LayerDesc& L = d.l[li];
+    const LayerDesc L = d.l[li];  // by value: registers, not an LDS reload after every LDS store
     const int nkt = (L.k + 31) / 32, nrt = (L.n + 31) / 32;
     const int cnt = L.n * L.k + L.n;
     for (int i = threadIdx.x; i < cnt; i += blockDim.x) s_red[i] = 0.0f;
@@ -352,13 +501,7 @@ mlp_bwd_kernel(const StackDesc d, const float* __restrict__ x, int64_t ldx, int6
         }
       }
     }
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int j = lane + 64 * half;
-#pragma unroll
-      for (int q = 0; q < kMaxLayers; ++q)
-        if (q == li && j < L.n) atomicAdd(s_red + L.n * L.k + j, db[q][half]);
-    }
+    for (int j = lane; j < L.n; j += 64) atomicAdd(s_red + L.n * L.k + j, s_dbv[wave * d.nsum + d.db_off[li] + j]);
     __syncthreads();
     for (int i = threadIdx.x; i < cnt; i += blockDim.x) ws[(int64_t)blockIdx.x * slab + off + i] = s_red[i];
     __syncthreads();
@@ -391,9 +534,13 @@ int build(const ctr_mlp_layer_t* layers, int nlayers, bool backward, Built* out)
     LayerDesc& L = d.l[i];
     L.w = s.w; L.b = s.b; L.y = s.y; L.ldy = s.ldy; L.gw = s.gw; L.gb = s.gb;
     L.n = s.n; L.k = s.k; L.act = s.act;
+    L.div_n = ctr_fastdiv((uint32_t)s.n);
+    L.div_k4 = ctr_fastdiv((uint32_t)(s.k / 4));
     L.w_off = woff;
     L.acc_off = tiles;
     woff += s.n * (s.k + 4);
+    L.b_off = woff;
+    woff += (s.n + 3) / 4 * 4;
     tiles += ((s.n + 31) / 32) * ((s.k + 31) / 32);
     maxk = s.k > maxk ? s.k : maxk;
     maxn = s.n > maxn ? s.n : maxn;
@@ -423,9 +570,16 @@ int build(const ctr_mlp_layer_t* layers, int nlayers, bool backward, Built* out)
     }
     d.sa = wa + 4;
     d.sb = wb + 4;
+    int nsum = 0;
+    for (int i = 0; i < nlayers; ++i) {
+      d.db_off[i] = nsum;
+      nsum += layers[i].n;
+    }
+    d.nsum = nsum;
     const int64_t tiles_floats = (int64_t)kWaves * 32 * (d.sa + d.sb);
-    const int64_t act_region = tiles_floats > biggest ? tiles_floats : biggest;
-    out->lds_bytes = sizeof(float) * (d.wfloats + act_region);
+    // the flush stages one layer's n*k + n sums over the tile region, which must hold it
+    CTR_REQUIRE(biggest <= tiles_floats, CTR_ELIMIT);
+    out->lds_bytes = sizeof(float) * (d.wfloats + tiles_floats + (int64_t)kWaves * nsum);
   } else {
     for (int i = 0; i < nlayers; ++i) {
       int& win = (i & 1) ? wb : wa;   // layer i reads tile A (even i) / B (odd i) ...
@@ -438,7 +592,7 @@ int build(const ctr_mlp_layer_t* layers, int nlayers, bool backward, Built* out)
     out->lds_bytes = sizeof(float) * (d.wfloats + (int64_t)kWaves * 32 * (d.sa + d.sb));
   }
   out->slab = slab;
-  CTR_REQUIRE(out->lds_bytes <= 160 * 1024, CTR_ELIMIT);
+  CTR_REQUIRE(out->lds_bytes + sizeof(StackDesc) <= 160 * 1024, CTR_ELIMIT);
   return CTR_OK;
 }
 
@@ -484,15 +638,24 @@ extern "C" int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp
   if (rc != CTR_OK) return rc;
   CTR_REQUIRE(ldx >= b.d.l[0].k && ldgy >= b.d.l[nlayers - 1].n && (!gx || ldgx >= b.d.l[0].k), CTR_EINVAL);
   CTR_REQUIRE(b.d.ntiles <= 16, CTR_ELIMIT);  // dW accumulators must fit the register file
+  const int maxt = b.d.ntiles <= 8 ? 8 : (b.d.ntiles <= 12 ? 12 : (b.d.ntiles <= 14 ? 14 : 16));
   const int64_t tiles = ctr_ceil_div(m, 32);
   int64_t grid = ctr_ceil_div(tiles, kWaves);
   if (grid > 256) grid = 256;
   CTR_REQUIRE(workspace_floats >= grid * b.slab, CTR_ELIMIT);
   hipStream_t st = (hipStream_t)stream;
-  rc = allow_lds(mlp_bwd_kernel<16>, b.lds_bytes);
-  if (rc != CTR_OK) return rc;
-  hipLaunchKernelGGL(mlp_bwd_kernel<16>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, st, b.d, x, ldx, m, gy, ldgy,
-                     gx, ldgx, workspace, b.slab);
+#define CTR_LAUNCH_BWD(T)                                                                                          \
+  do {                                                                                                             \
+    rc = allow_lds(mlp_bwd_kernel<T>, b.lds_bytes);                                                                \
+    if (rc != CTR_OK) return rc;                                                                                   \
+    hipLaunchKernelGGL(mlp_bwd_kernel<T>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, st, b.d, x, ldx, m, gy, \
+                       ldgy, gx, ldgx, workspace, b.slab);                                                         \
+  } while (0)
+  if (maxt == 8) CTR_LAUNCH_BWD(8);
+  else if (maxt == 12) CTR_LAUNCH_BWD(12);
+  else if (maxt == 14) CTR_LAUNCH_BWD(14);
+  else CTR_LAUNCH_BWD(16);
+#undef CTR_LAUNCH_BWD
   rc = ctr_launch_status();
   if (rc != CTR_OK) return rc;
   CtrSegments segs;
