@@ -15,7 +15,7 @@ import torch  # noqa: F401  (maps libamdhip64 first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTRHIP_LIB", os.path.join(_HERE, "libctrhip.so"))  # env override: A/B builds
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 CTR_MAX_FIELDS = 32
 FIELD_ID_I64, FIELD_ID_F32, FIELD_BAG, FIELD_DENSE, FIELD_PROD_I64 = range(5)
@@ -72,6 +72,7 @@ SIGNATURES = {
     "ctr_gru_bwd": (_i, [_p, _l, _p, _p, _p, _l, _i, _i, _p, _l, _p, _p, _p]),
     "ctr_mlp_fwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, _p]),
     "ctr_mlp_bwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, _p, _l, _p, _l, _p, _l, _p]),
+    "ctr_shard_bucket": (_i, [_p, _l, _i, _p, _p, _p, _p, _p, _p]),
 }
 
 _lock = threading.Lock()

@@ -409,3 +409,42 @@ def test_fused_mlp_matches_layerwise_and_fp64(ops, m, dims, acts_):
     for (gw, gb), (rw, rb) in zip(grads_f, ref):
         torch.testing.assert_close(gw.cpu(), rw.float(), rtol=1e-4, atol=1e-5 * scale)
         torch.testing.assert_close(gb.cpu(), rb.float(), rtol=1e-4, atol=1e-5 * scale)
+
+
+@pytest.mark.parametrize("n,world", [(100000, 8), (37, 2), (1, 3), (0, 4), (5000, 1)])
+def test_shard_bucket_kernel(n, world):
+    from deeplearningrecommendationsystem_amd.dist import HipShardBackend
+    g = torch.Generator().manual_seed(n + world)
+    ids = torch.randint(0, 1_000_000, (n,), generator=g)
+    counts, send, perm, inv = HipShardBackend.bucket(ids.to(DEV), world)
+    counts, send, perm, inv = counts.cpu(), send.cpu(), perm.cpu(), inv.cpu()
+    assert counts.tolist() == torch.bincount(ids % world, minlength=world).tolist()
+    assert sorted(perm.tolist()) == list(range(n))                       # a permutation
+    assert torch.equal(inv[perm], torch.arange(n))                       # inv is its inverse
+    assert torch.equal(send[perm], ids // world)                         # slot holds the local row
+    starts = torch.cumsum(counts, 0) - counts
+    owner_of_slot = torch.bucketize(torch.arange(n), torch.cumsum(counts, 0), right=True)
+    assert torch.equal(owner_of_slot[perm], ids % world)                 # buckets are in rank order
+
+
+def test_sharded_embedding_single_rank_on_gpu():
+    import os
+    import torch.distributed as dist
+    from deeplearningrecommendationsystem_amd.dist import ShardedEmbedding
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        torch.manual_seed(0)
+        full = torch.randn(5000, 16)
+        emb = ShardedEmbedding(5000, 16, device=DEV)
+        emb.load_full_table(full.to(DEV))
+        ids = torch.randint(0, 5000, (300, 7))
+        got = emb(ids.to(DEV))
+        assert torch.equal(got.cpu(), full[ids])
+        gout = torch.randn(300, 7, 16)
+        got.backward(gout.to(DEV))
+        ref = torch.zeros(5000, 16).index_put_((ids.reshape(-1),), gout.reshape(-1, 16), accumulate=True)
+        torch.testing.assert_close(emb.weight.grad.cpu(), ref, rtol=1e-5, atol=1e-5)
+    finally:
+        dist.destroy_process_group()
