@@ -15,7 +15,7 @@ import torch  # noqa: F401  (maps libamdhip64 first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTRHIP_LIB", os.path.join(_HERE, "libctrhip.so"))  # env override: A/B builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 CTR_MAX_FIELDS = 32
 FIELD_ID_I64, FIELD_ID_F32, FIELD_BAG, FIELD_DENSE, FIELD_PROD_I64 = range(5)
@@ -39,6 +39,12 @@ class MlpLayer(C.Structure):
     _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("y", C.c_void_p), ("ldy", C.c_int64),
                 ("gw", C.c_void_p), ("gb", C.c_void_p), ("n", C.c_int32), ("k", C.c_int32), ("act", C.c_int32),
                 ("reserved", C.c_int32)]
+
+
+class AdamTensor(C.Structure):
+    """mirror of ``ctr_adam_tensor_t``"""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("numel", C.c_int64)]
 
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -73,6 +79,9 @@ SIGNATURES = {
     "ctr_mlp_fwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, _p]),
     "ctr_mlp_bwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, _p, _l, _p, _l, _p, _l, _p]),
     "ctr_shard_bucket": (_i, [_p, _l, _i, _p, _p, _p, _p, _p, _p]),
+    "ctr_bce_fwd": (_i, [_p, _l, _p, _l, _l, _p, _p, _l, _p]),
+    "ctr_bce_bwd": (_i, [_p, _l, _p, _l, _l, _p, _p, _l, _p]),
+    "ctr_adam_step": (_i, [C.POINTER(AdamTensor), _i, _f, _f, _f, _f, _f, _l, _p]),
 }
 
 _lock = threading.Lock()

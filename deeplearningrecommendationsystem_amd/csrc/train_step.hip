@@ -1,0 +1,140 @@
+// The two non-model pieces of a Trainer.train_loop body (trainer/trainer.py:37-39):
+//   * torch.nn.BCELoss() (every script, e.g. scripts/pnn.py:54): mean over the batch of
+//     -[y*max(log p,-100) + (1-y)*max(log(1-p),-100)], and its gradient
+//     (p - y) / max(p(1-p), 1e-12) * gloss / n          -- ATen's formulas, one pass each;
+//   * torch.optim.Adam(lr, betas, eps, weight_decay) (e.g. scripts/pnn.py:55): dense Adam
+//     with L2 decay over every parameter, all tensors in ONE launch, 4 reads + 3 writes
+//     per element (g, p, m, v -> p, m, v): HBM-bound, 28 B per parameter.
+#include "ctr_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__global__ void __launch_bounds__(kBlock)
+bce_partial_kernel(const float* __restrict__ p, int64_t ldp, const float* __restrict__ y, int64_t ldy, int64_t n,
+                   float inv_n, float* __restrict__ partial) {
+  __shared__ float s_red[kBlock / 64];
+  float acc = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float pv = p[i * ldp], yv = y[i * ldy];
+    const float lp = fmaxf(logf(pv), -100.0f), l1p = fmaxf(logf(1.0f - pv), -100.0f);
+    acc -= yv * lp + (1.0f - yv) * l1p;
+  }
+  acc = ctr_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+    for (int w = 0; w < kBlock / 64; ++w) t += s_red[w];
+    partial[blockIdx.x] = t * inv_n;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+bce_bwd_kernel(const float* __restrict__ p, int64_t ldp, const float* __restrict__ y, int64_t ldy, int64_t n,
+               const float* __restrict__ gloss, float inv_n, float* __restrict__ gp, int64_t ldg) {
+  const float scale = gloss[0] * inv_n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float pv = p[i * ldp], yv = y[i * ldy];
+    gp[i * ldg] = (pv - yv) / fmaxf((1.0f - pv) * pv, 1e-12f) * scale;
+  }
+}
+
+struct AdamPack {
+  ctr_adam_tensor_t t[CTR_ADAM_MAX_TENSORS];
+  int n;
+};
+
+__global__ void __launch_bounds__(kBlock)
+adam_kernel(const AdamPack P, float lr, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt) {
+  const ctr_adam_tensor_t t = P.t[blockIdx.y];
+  const float step_size = lr / bc1;
+  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < t.numel; i += (int64_t)gridDim.x * blockDim.x * 4) {
+    if (i + 3 < t.numel) {
+      float4 g = *reinterpret_cast<const float4*>(t.grad + i);
+      float4 p = *reinterpret_cast<const float4*>(t.param + i);
+      float4 m = *reinterpret_cast<const float4*>(t.exp_avg + i);
+      float4 v = *reinterpret_cast<const float4*>(t.exp_avg_sq + i);
+      float* gg = &g.x; float* pp = &p.x; float* mm = &m.x; float* vv = &v.x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gr = fmaf(weight_decay, pp[e], gg[e]);     // grad.add(param, alpha=wd)
+        mm[e] = fmaf(1.0f - beta1, gr - mm[e], mm[e]);           // exp_avg.lerp_(grad, 1 - beta1)
+        vv[e] = vv[e] * beta2 + ((1.0f - beta2) * gr) * gr;      // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+        pp[e] -= step_size * (mm[e] / denom);
+      }
+      *reinterpret_cast<float4*>(t.param + i) = p;
+      *reinterpret_cast<float4*>(t.exp_avg + i) = m;
+      *reinterpret_cast<float4*>(t.exp_avg_sq + i) = v;
+    } else {
+      for (int64_t j = i; j < t.numel; ++j) {
+        const float gr = fmaf(weight_decay, t.param[j], t.grad[j]);
+        const float m = fmaf(1.0f - beta1, gr - t.exp_avg[j], t.exp_avg[j]);
+        const float v = t.exp_avg_sq[j] * beta2 + ((1.0f - beta2) * gr) * gr;
+        t.exp_avg[j] = m;
+        t.exp_avg_sq[j] = v;
+        t.param[j] -= step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ctr_bce_fwd(const float* prob, int64_t ldp, const float* target, int64_t ldt, int64_t n, float* loss,
+                           float* workspace, int64_t workspace_floats, void* stream) {
+  CTR_REQUIRE(n > 0 && prob && target && loss && workspace && ldp >= 1 && ldt >= 1, CTR_EINVAL);
+  int64_t grid = ctr_ceil_div(n, kBlock * 4);
+  if (grid > 256) grid = 256;
+  CTR_REQUIRE(workspace_floats >= grid, CTR_ELIMIT);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return CTR_ELAUNCH;
+  hipLaunchKernelGGL(bce_partial_kernel, dim3((unsigned)grid), dim3(kBlock), 0, st, prob, ldp, target, ldt, n,
+                     1.0f / (float)n, workspace);
+  int rc = ctr_launch_status();
+  if (rc != CTR_OK) return rc;
+  CtrSegments segs;
+  segs.n = 1;
+  segs.s[0] = CtrSegment{0, 1, loss};
+  return ctr_reduce_segments(workspace, (int)grid, 1, segs, st);
+}
+
+extern "C" int ctr_bce_bwd(const float* prob, int64_t ldp, const float* target, int64_t ldt, int64_t n,
+                           const float* gloss, float* gprob, int64_t ldg, void* stream) {
+  CTR_REQUIRE(n > 0 && prob && target && gloss && gprob && ldp >= 1 && ldt >= 1 && ldg >= 1, CTR_EINVAL);
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3(ctr_stream_grid(n, kBlock)), dim3(kBlock), 0, (hipStream_t)stream, prob, ldp,
+                     target, ldt, n, gloss, 1.0f / (float)n, gprob, ldg);
+  return ctr_launch_status();
+}
+
+extern "C" int ctr_adam_step(const ctr_adam_tensor_t* tensors, int ntensors, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int64_t step, void* stream) {
+  CTR_REQUIRE(tensors && ntensors >= 0 && step >= 1, CTR_EINVAL);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipStream_t st = (hipStream_t)stream;
+  for (int base = 0; base < ntensors; base += CTR_ADAM_MAX_TENSORS) {
+    AdamPack P;
+    P.n = ntensors - base < CTR_ADAM_MAX_TENSORS ? ntensors - base : CTR_ADAM_MAX_TENSORS;
+    int64_t longest = 0;
+    for (int i = 0; i < P.n; ++i) {
+      const ctr_adam_tensor_t& t = tensors[base + i];
+      CTR_REQUIRE(t.param && t.grad && t.exp_avg && t.exp_avg_sq && t.numel >= 0, CTR_EINVAL);
+      CTR_REQUIRE(ctr_aligned16(t.param) && ctr_aligned16(t.grad) && ctr_aligned16(t.exp_avg) &&
+                      ctr_aligned16(t.exp_avg_sq),
+                  CTR_EALIGN);
+      P.t[i] = t;
+      longest = t.numel > longest ? t.numel : longest;
+    }
+    if (longest == 0) continue;
+    int64_t gx = ctr_ceil_div(longest, kBlock * 4);
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gx, (unsigned)P.n), dim3(kBlock), 0, st, P, lr, beta1, beta2, eps,
+                       weight_decay, (float)bc1, (float)sqrt(bc2));
+    int rc = ctr_launch_status();
+    if (rc != CTR_OK) return rc;
+  }
+  return CTR_OK;
+}

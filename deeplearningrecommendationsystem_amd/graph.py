@@ -24,6 +24,9 @@ class GraphedStep:
         self.model, self.loss_fn = model, loss_fn
         self.inputs, self.target = list(inputs), target
         model.train()
+        # warm-up runs on a side stream, capture on the graph's stream: the AccumulateGrad nodes
+        # are recreated per iteration, the stream-mismatch warning does not apply
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

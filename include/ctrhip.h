@@ -276,6 +276,34 @@ int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* l
 int ctr_shard_bucket(const int64_t* ids, int64_t n, int world, int64_t* counts, int64_t* cursor,
                      int64_t* send, int64_t* perm, int64_t* inv, void* stream);
 
+/* ------------------------------------------------------------------------
+ * The rest of a train_loop body (trainer/trainer.py:37-39).
+ * ---------------------------------------------------------------------- */
+
+/* torch.nn.BCELoss() with mean reduction (every script, e.g. scripts/pnn.py:54):
+ * loss[0] = mean_i -[t_i*max(log p_i,-100) + (1-t_i)*max(log(1-p_i),-100)].
+ * prob/target: element i at [i*ld]; workspace: >= 256 floats of device scratch. */
+int ctr_bce_fwd(const float* prob, int64_t ldp, const float* target, int64_t ldt, int64_t n, float* loss,
+                float* workspace, int64_t workspace_floats, void* stream);
+/* gprob[i*ldg] = (p_i - t_i) / max(p_i (1-p_i), 1e-12) * gloss[0] / n */
+int ctr_bce_bwd(const float* prob, int64_t ldp, const float* target, int64_t ldt, int64_t n,
+                const float* gloss, float* gprob, int64_t ldg, void* stream);
+
+/* torch.optim.Adam(params, lr, betas, eps, weight_decay) (e.g. scripts/pnn.py:55), one
+ * step over all tensors in one launch (16-byte aligned, contiguous fp32):
+ *   g += wd*p; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g;
+ *   p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps).   tensors: host array. */
+#define CTR_ADAM_MAX_TENSORS 64
+typedef struct ctr_adam_tensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t numel;
+} ctr_adam_tensor_t;
+int ctr_adam_step(const ctr_adam_tensor_t* tensors, int ntensors, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int64_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

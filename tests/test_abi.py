@@ -100,6 +100,10 @@ def _parse_header_prototypes():
                     kinds.append("field*")
                 elif "ctr_mlp_layer_t" in a:
                     kinds.append("mlp*")
+                elif "ctr_adam_tensor_t" in a:
+                    kinds.append("adam*")
+                elif a.startswith("float "):
+                    kinds.append("f32")
                 elif "int32_t*" in a.replace(" *", "*") and "const" in a:
                     kinds.append("i32*")
                 elif "*" in a:
@@ -129,6 +133,10 @@ def test_ctypes_signatures_match_header_prototypes(lib):
                 got.append("field*")
             elif a is ctypes.POINTER(lib.MlpLayer):
                 got.append("mlp*")
+            elif a is ctypes.POINTER(lib.AdamTensor):
+                got.append("adam*")
+            elif a is ctypes.c_float:
+                got.append("f32")
             elif a is ctypes.POINTER(ctypes.c_int32):
                 got.append("i32*")
             else:

@@ -171,3 +171,44 @@ def test_dien_config5_shape_against_oracle():
     torch.manual_seed(9)
     inputs, y = _sequence_case(2048, 100, 100_000, 19)
     _vs_oracle("dien", DIEN(100_000, 16), inputs, y)
+
+
+def test_trainer_mirror_trains_neuralcf_eager_and_graphed():
+    # Trainer call convention of trainer/trainer.py:23-78 on the HIP module; the graphed
+    # step must produce the same parameter updates as the eager one
+    from torch import optim
+    from deeplearningrecommendationsystem_amd import synth
+    from deeplearningrecommendationsystem_amd.model import NeuralCF
+    from deeplearningrecommendationsystem_amd.trainer import Trainer
+    gen = synth.generator(5)
+    u, i = synth.id_batch(4096, 50, 60, gen)
+    y = ((u + i) % 2 == 0).float().view(-1, 1)
+    u, i, y = u.to(DEV), i.to(DEV), y.to(DEV)
+    finals = []
+    for graph in (False, True):
+        torch.manual_seed(0)
+        m = NeuralCF(50, 60, 8, [16, 8]).to(DEV)
+        t = Trainer(m, torch.nn.BCELoss(), optim.Adam(m.parameters(), lr=0.01, weight_decay=1e-5), graph=graph)
+        first = None
+        for _ in range(30):
+            t.train_loop(u, i, train_rating=y)
+            first = first if first is not None else t.train_loss.item()
+        t.valid_loop(u, i, valid_rating=y)
+        t.test_loop(u, i, test_rating=y)
+        tr, va, te = t.model_eval(0)
+        assert t.train_loss.item() < first            # it learns
+        assert 0.0 <= va[4] <= 1.0
+        finals.append(t.valid_loss.item())
+    assert abs(finals[0] - finals[1]) < 1e-3 * max(1.0, abs(finals[0]))
+    with pytest.raises(ValueError):
+        t.train_loop(u, i, y, train_rating=y)
+
+
+def test_evaluator_matches_definitions():
+    from deeplearningrecommendationsystem_amd.evaluator import Evaluator
+    y = torch.tensor([1., 0., 1., 1., 0., 0.])
+    p = torch.tensor([0.9, 0.8, 0.4, 0.6, 0.2, 0.6])
+    acc, prec, rec, f1, auc = Evaluator.eval(y, p)
+    assert abs(acc - 3 / 6) < 1e-6 and abs(prec - 2 / 4) < 1e-6 and abs(rec - 2 / 3) < 1e-6
+    # pairs (pos, neg): 9 pairs; pos>neg: (.9: 3) + (.4: 1) + (.6: 1 + tie .5) = 5.5
+    assert abs(auc - 5.5 / 9) < 1e-6
