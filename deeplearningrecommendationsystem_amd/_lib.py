@@ -81,7 +81,7 @@ SIGNATURES = {
     "ctr_shard_bucket": (_i, [_p, _l, _i, _p, _p, _p, _p, _p, _p]),
     "ctr_bce_fwd": (_i, [_p, _l, _p, _l, _l, _p, _p, _l, _p]),
     "ctr_bce_bwd": (_i, [_p, _l, _p, _l, _l, _p, _p, _l, _p]),
-    "ctr_adam_step": (_i, [C.POINTER(AdamTensor), _i, _f, _f, _f, _f, _f, _l, _p]),
+    "ctr_adam_step": (_i, [C.POINTER(AdamTensor), _i, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _l, _p]),
 }
 
 _lock = threading.Lock()

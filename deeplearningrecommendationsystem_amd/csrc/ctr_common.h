@@ -117,3 +117,4 @@ int ctr_n1_fwd(const float* x, int64_t ldx, const float* w, const float* bias, c
 int ctr_n1_bwd(const float* x, int64_t ldx, const float* w, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
                float* gx, int64_t ldgx, int accumulate_gx, float* gw, float* gb, int64_t m, int k, int act,
                float* ws, int64_t ws_floats, hipStream_t st);
+

@@ -284,6 +284,9 @@ struct PairList {
   int n;
   unsigned char a[kMaxPairs];
   unsigned char b[kMaxPairs];
+  // backward view: vector f pairs with partner[start[f] .. start[f+1])
+  unsigned char start[65];
+  unsigned char partner[2 * kMaxPairs];
 };
 
 // prob[b] = sigmoid(user1[u] + item1[i] + sum_c (x[b,c] + cross) w[c] + wb),
@@ -384,14 +387,10 @@ ffm_head_bwd_kernel(const Geometry g, const float* __restrict__ emb, int64_t lde
         float acc[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] = 0.0f;
-        for (int p = 0; p < pl.n; ++p) {
-          int other = -1;
-          if (pl.a[p] == f) other = pl.b[p];
-          else if (pl.b[p] == f) other = pl.a[p];
-          if (other >= 0) {
+        for (int q = pl.start[f]; q < pl.start[f + 1]; ++q) {
+          const int other = pl.partner[q];
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[v] += base[other * g.estride + v];
-          }
+          for (int v = 0; v < VEC; ++v) acc[v] += base[other * g.estride + v];
         }
         float* dst = gemb + (b0 + s) * ldg + f * g.e + c;
 #pragma unroll
@@ -578,6 +577,16 @@ static int make_pairs(const int32_t* pairs, int npairs, int nvec, PairList* pl) 
     pl->a[p] = (unsigned char)a;
     pl->b[p] = (unsigned char)b;
   }
+  int q = 0;
+  for (int f = 0; f < nvec && f < 64; ++f) {
+    pl->start[f] = (unsigned char)q;
+    for (int p = 0; p < npairs; ++p) {
+      if (pairs[2 * p] == f) pl->partner[q++] = (unsigned char)pairs[2 * p + 1];
+      else if (pairs[2 * p + 1] == f) pl->partner[q++] = (unsigned char)pairs[2 * p];
+    }
+  }
+  for (int f = nvec; f <= 64; ++f) pl->start[f] = (unsigned char)q;
+  pl->start[nvec < 64 ? nvec : 64] = (unsigned char)q;
   return CTR_OK;
 }
 

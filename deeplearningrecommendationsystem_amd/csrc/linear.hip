@@ -51,13 +51,15 @@ struct PlainSrc {
     }
     return v;
   }
-  // interior tile: no bounds checks, straight-line code the scheduler can slide under MFMAs
+  // fast path: one predicated dwordx4, no branches -- straight-line code the scheduler can
+  // slide under the MFMAs.  Needs 16-B aligned rows and cols % 4 == 0 (then c < cols covers
+  // the whole vector); out-of-range rows / columns read as zero.
   __device__ __forceinline__ float4 load4_fast(int64_t r, int64_t c) const {
-    return *reinterpret_cast<const float4*>(p + r * ld + c);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows && c < cols) v = *reinterpret_cast<const float4*>(p + r * ld + c);
+    return v;
   }
-  __device__ __forceinline__ bool interior(int64_t r0, int64_t nr, int64_t c0, int64_t nc) const {
-    return vec && r0 + nr <= rows && c0 + nc <= cols;
-  }
+  __device__ __forceinline__ bool fast_ok() const { return vec && (cols % 4 == 0); }
 };
 
 // gZ = gY * act'(Y), formed on the fly from the saved layer output
@@ -76,9 +78,7 @@ struct GzSrc {
     }
     return g;
   }
-  __device__ __forceinline__ bool interior(int64_t r0, int64_t nr, int64_t c0, int64_t nc) const {
-    return gy.interior(r0, nr, c0, nc) && (act == CTR_ACT_NONE || y.interior(r0, nr, c0, nc));
-  }
+  __device__ __forceinline__ bool fast_ok() const { return gy.fast_ok() && (act == CTR_ACT_NONE || y.fast_ok()); }
   __device__ __forceinline__ float4 load4_fast(int64_t r, int64_t c) const {
     float4 g = gy.load4_fast(r, c);
     if (act != CTR_ACT_NONE) {
@@ -226,7 +226,6 @@ gemm_tile_kernel(const ASrc a, const BSrc b, const Epi epi, int64_t M, int N, in
   const int64_t kb = (int64_t)blockIdx.z * k_chunk;
   const int64_t ke = kb + k_chunk < K ? kb + k_chunk : K;
   const int nk = (int)((ke - kb + kBK - 1) / kBK);
-  const int full = (int)((ke - kb) / kBK);  // steps whose 32 contraction indices all exist
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -244,19 +243,19 @@ gemm_tile_kernel(const ASrc a, const BSrc b, const Epi epi, int64_t M, int N, in
       for (int e = 0; e < 16; ++e) acc[n][c][e] = 0.0f;
   float colsum = 0.0f;
 
-  // operand tiles that lie wholly inside their matrices take the unguarded load path
-  const bool a_in = AMODE == KC ? a.interior(i0, kBM, 0, 0) : a.interior(0, 0, i0, kBM);
-  const bool b_in = BMODE == KC ? b.interior(j0, BN, 0, 0) : b.interior(0, 0, j0, BN);
+  // aligned operands take the branch-free predicated load path for every tile
+  const bool a_in = a.fast_ok();
+  const bool b_in = b.fast_ok();
 
   AStage sa;
   BStage sb;
-  sa.load(a, i0, kb, a_in && full > 0);
-  sb.load(b, j0, kb, b_in && full > 0);
+  sa.load(a, i0, kb, a_in);
+  sb.load(b, j0, kb, b_in);
   sa.store(s_a[0]);
   sb.store(s_b[0]);
   if (nk > 1) {
-    sa.load(a, i0, kb + kBK, a_in && full > 1);
-    sb.load(b, j0, kb + kBK, b_in && full > 1);
+    sa.load(a, i0, kb + kBK, a_in);
+    sb.load(b, j0, kb + kBK, b_in);
   }
   __syncthreads();
   for (int ks = 0; ks < nk; ++ks) {
@@ -267,8 +266,8 @@ gemm_tile_kernel(const ASrc a, const BSrc b, const Epi epi, int64_t M, int N, in
     }
     if (ks + 2 < nk) {
       const int64_t k2 = kb + (int64_t)(ks + 2) * kBK;
-      sa.load(a, i0, k2, a_in && ks + 2 < full);
-      sb.load(b, j0, k2, b_in && ks + 2 < full);
+      sa.load(a, i0, k2, a_in);
+      sb.load(b, j0, k2, b_in);
     }
     float fa[16];
     read_frag<AMODE, kBM>(s_a[cur], 32 * wave + r, h, fa);
@@ -407,10 +406,12 @@ extern "C" int ctr_linear_bwd(const float* x, int64_t ldx, const float* w, int64
     // gW[n][kcol] += sum_m gZ[m][n] X[m][kcol]: contraction = m, split over workgroups
     GzSrc gzt = gz;  // indexed (r = m, c = n): KS operand of the transposed product
     const int64_t tiles = ctr_ceil_div(n, kBM) * ctr_ceil_div(k, 32 * pick_nt(k));
-    int64_t splits = (1024 + tiles - 1) / tiles;           // ~4 workgroups per CU
+    // enough row chunks for ~6 resident workgroups per CU: the chunks stream gY, Y and X once
+    // and only occupancy hides their HBM latency (256 chunks = 1 workgroup per CU ran 4x slower)
+    const int64_t target = tiles >= 4 ? 1024 : 1536;
+    int64_t splits = (target + tiles - 1) / tiles;
     const int64_t max_splits = ctr_ceil_div(m, 4 * kBK);   // at least 128 rows each
     if (splits > max_splits) splits = max_splits;
-    if (splits > 256) splits = 256;
     if (splits < 1) splits = 1;
     CTR_REQUIRE(gw != nullptr, CTR_EINVAL);  // gb without gw is not used by any model
     // every chunk adds its partial to the same n*k outputs.  More than a handful of

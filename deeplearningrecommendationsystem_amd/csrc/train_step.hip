@@ -47,7 +47,8 @@ struct AdamPack {
 };
 
 __global__ void __launch_bounds__(kBlock)
-adam_kernel(const AdamPack P, float lr, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt) {
+adam_kernel(const AdamPack P, float lr, float beta2, float omb1, float omb2, float eps, float weight_decay, float bc1,
+            float bc2_sqrt) {  // omb = 1 - beta, formed in double on the host as torch does
   const ctr_adam_tensor_t t = P.t[blockIdx.y];
   const float step_size = lr / bc1;
   for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < t.numel; i += (int64_t)gridDim.x * blockDim.x * 4) {
@@ -60,8 +61,8 @@ adam_kernel(const AdamPack P, float lr, float beta1, float beta2, float eps, flo
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float gr = fmaf(weight_decay, pp[e], gg[e]);     // grad.add(param, alpha=wd)
-        mm[e] = fmaf(1.0f - beta1, gr - mm[e], mm[e]);           // exp_avg.lerp_(grad, 1 - beta1)
-        vv[e] = vv[e] * beta2 + ((1.0f - beta2) * gr) * gr;      // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        mm[e] = fmaf(omb1, gr - mm[e], mm[e]);           // exp_avg.lerp_(grad, 1 - beta1)
+        vv[e] = vv[e] * beta2 + (omb2 * gr) * gr;      // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
         const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
         pp[e] -= step_size * (mm[e] / denom);
       }
@@ -71,8 +72,8 @@ adam_kernel(const AdamPack P, float lr, float beta1, float beta2, float eps, flo
     } else {
       for (int64_t j = i; j < t.numel; ++j) {
         const float gr = fmaf(weight_decay, t.param[j], t.grad[j]);
-        const float m = fmaf(1.0f - beta1, gr - t.exp_avg[j], t.exp_avg[j]);
-        const float v = t.exp_avg_sq[j] * beta2 + ((1.0f - beta2) * gr) * gr;
+        const float m = fmaf(omb1, gr - t.exp_avg[j], t.exp_avg[j]);
+        const float v = t.exp_avg_sq[j] * beta2 + (omb2 * gr) * gr;
         t.exp_avg[j] = m;
         t.exp_avg_sq[j] = v;
         t.param[j] -= step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
@@ -109,11 +110,11 @@ extern "C" int ctr_bce_bwd(const float* prob, int64_t ldp, const float* target, 
   return ctr_launch_status();
 }
 
-extern "C" int ctr_adam_step(const ctr_adam_tensor_t* tensors, int ntensors, float lr, float beta1, float beta2,
-                             float eps, float weight_decay, int64_t step, void* stream) {
+extern "C" int ctr_adam_step(const ctr_adam_tensor_t* tensors, int ntensors, double lr, double beta1, double beta2,
+                             double eps, double weight_decay, int64_t step, void* stream) {
   CTR_REQUIRE(tensors && ntensors >= 0 && step >= 1, CTR_EINVAL);
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
   hipStream_t st = (hipStream_t)stream;
   for (int base = 0; base < ntensors; base += CTR_ADAM_MAX_TENSORS) {
     AdamPack P;
@@ -131,8 +132,9 @@ extern "C" int ctr_adam_step(const ctr_adam_tensor_t* tensors, int ntensors, flo
     if (longest == 0) continue;
     int64_t gx = ctr_ceil_div(longest, kBlock * 4);
     if (gx > 2048) gx = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gx, (unsigned)P.n), dim3(kBlock), 0, st, P, lr, beta1, beta2, eps,
-                       weight_decay, (float)bc1, (float)sqrt(bc2));
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)gx, (unsigned)P.n), dim3(kBlock), 0, st, P, (float)lr,
+                       (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay,
+                       (float)bc1, (float)sqrt(bc2));
     int rc = ctr_launch_status();
     if (rc != CTR_OK) return rc;
   }

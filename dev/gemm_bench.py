@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from deeplearningrecommendationsystem_amd import ops
 
-shapes = [(65536, 256, 512), (65536, 512, 96), (65536, 128, 256), (65536, 64, 128), (65536, 256, 161), (3276800, 128, 192), (3276800, 64, 128)]
+shapes = [(65536, 256, 512), (65536, 512, 96), (65536, 128, 256), (65536, 64, 128), (65536, 8, 16), (65536, 256, 164), (3276800, 128, 192), (3276800, 64, 128), (3276800, 64, 48), (3276800, 32, 64)]
 if len(sys.argv) > 1:
     shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
 dev = "cuda:0"

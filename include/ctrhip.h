@@ -301,8 +301,8 @@ typedef struct ctr_adam_tensor {
   float* exp_avg_sq;
   int64_t numel;
 } ctr_adam_tensor_t;
-int ctr_adam_step(const ctr_adam_tensor_t* tensors, int ntensors, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int64_t step, void* stream);
+int ctr_adam_step(const ctr_adam_tensor_t* tensors, int ntensors, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, int64_t step, void* stream);
 
 #ifdef __cplusplus
 }

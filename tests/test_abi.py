@@ -104,6 +104,8 @@ def _parse_header_prototypes():
                     kinds.append("adam*")
                 elif a.startswith("float "):
                     kinds.append("f32")
+                elif a.startswith("double "):
+                    kinds.append("f64")
                 elif "int32_t*" in a.replace(" *", "*") and "const" in a:
                     kinds.append("i32*")
                 elif "*" in a:
@@ -137,6 +139,8 @@ def test_ctypes_signatures_match_header_prototypes(lib):
                 got.append("adam*")
             elif a is ctypes.c_float:
                 got.append("f32")
+            elif a is ctypes.c_double:
+                got.append("f64")
             elif a is ctypes.POINTER(ctypes.c_int32):
                 got.append("i32*")
             else:
