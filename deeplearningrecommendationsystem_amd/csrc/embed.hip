@@ -105,7 +105,7 @@ embed_fwd_kernel(const FieldPack P, int nfields, const float* __restrict__ x, in
     const uint32_t b = ctr_div(g, div);
     const uint32_t u = g - b * upr;
     const int fi = s.field_of[u];
-    const ctr_field_t& f = s.f[fi];
+    const ctr_field_t f = s.f[fi];  // by value: one batch of LDS reads, not a reload after every store
     const int off = (int)(u - (uint32_t)s.start[fi]) * VEC;
     V v;
     switch (f.kind) {
@@ -171,7 +171,7 @@ embed_bwd_kernel(const FieldPack P, int nfields, const float* __restrict__ x, in
     const uint32_t b = ctr_div(g, div);
     const uint32_t u = g - b * upr;
     const int fi = s.field_of[u];
-    const ctr_field_t& f = s.f[fi];
+    const ctr_field_t f = s.f[fi];  // by value (see the forward kernel)
     if (f.kind == CTR_FIELD_DENSE) continue;
     const int off = (int)(u - (uint32_t)s.start[fi]) * VEC;
     const V gv = *reinterpret_cast<const V*>(gout + (int64_t)b * ldo + f.out_col + off);

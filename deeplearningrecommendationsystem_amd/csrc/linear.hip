@@ -51,15 +51,24 @@ struct PlainSrc {
     }
     return v;
   }
-  // fast path: one predicated dwordx4, no branches -- straight-line code the scheduler can
-  // slide under the MFMAs.  Needs 16-B aligned rows and cols % 4 == 0 (then c < cols covers
-  // the whole vector); out-of-range rows / columns read as zero.
+  // fast path: one predicated dwordx4 -- straight-line code the scheduler can slide under
+  // the MFMAs.  Needs 16-B aligned rows; out-of-range rows / columns read as zero.  Only the
+  // last partial vector of a row whose length is not a multiple of 4 takes the scalar tail.
   __device__ __forceinline__ float4 load4_fast(int64_t r, int64_t c) const {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < rows && c < cols) v = *reinterpret_cast<const float4*>(p + r * ld + c);
+    if (r < rows) {
+      const float* q = p + r * ld + c;
+      if (c + 3 < cols) {
+        v = *reinterpret_cast<const float4*>(q);
+      } else if (c < cols) {
+        v.x = q[0];
+        if (c + 1 < cols) v.y = q[1];
+        if (c + 2 < cols) v.z = q[2];
+      }
+    }
     return v;
   }
-  __device__ __forceinline__ bool fast_ok() const { return vec && (cols % 4 == 0); }
+  __device__ __forceinline__ bool fast_ok() const { return vec; }
 };
 
 // gZ = gY * act'(Y), formed on the fly from the saved layer output

@@ -81,12 +81,12 @@ class DeepCrossing(FeatureModel):
         rs, hs = [r], []
         for k in range(len(self.res_layers)):
             w1, b1, w2, b2 = params[7 + 4 * k: 11 + 4 * k]
-            h = ops.linear_fwd(rs[-1], w1, b1, ACT_RELU)
+            h = ops.linear_fwd(rs[-1], self._aligned_weight(w1), b1, ACT_RELU)
             out = self._stack_buffer(batch, width, x.device)
             ops.linear_fwd(h, w2, b2, ACT_RELU, out=out, residual=rs[-1])
             hs.append(h)
             rs.append(out)
-        prob = ops.linear_fwd(rs[-1], lin_w, lin_b, ACT_SIGMOID)
+        prob = ops.linear_fwd(rs[-1], self._aligned_weight(lin_w), lin_b, ACT_SIGMOID)
         return prob, (rs, hs, prob)
 
     def run_backward(self, state, inputs, params, gprob):
@@ -98,7 +98,7 @@ class DeepCrossing(FeatureModel):
         zeros = ops.zero_grads(params)
         g_lin_w, g_lin_b = zeros[id(lin_w)], zeros[id(lin_b)]
         gr = self._stack_buffer(batch, width, x.device)
-        ops.linear_bwd(rs[-1], lin_w, prob, gprob, ACT_SIGMOID, gr, g_lin_w, g_lin_b)
+        ops.linear_bwd(rs[-1], self._aligned_weight(lin_w, refresh=False), prob, gprob, ACT_SIGMOID, gr, g_lin_w, g_lin_b)
         block_grads = []
         for k in range(len(self.res_layers) - 1, -1, -1):
             w1, b1, w2, b2 = params[7 + 4 * k: 11 + 4 * k]
@@ -107,7 +107,7 @@ class DeepCrossing(FeatureModel):
             gh = torch.empty_like(h)
             ops.linear_bwd(h, w2, r_out, gr, ACT_RELU, gh, gw2, gb2)            # through relu(linear2(h)+r)
             gr_in = self._stack_buffer(batch, width, x.device)
-            ops.linear_bwd(r_in, w1, h, gh, ACT_RELU, gr_in, gw1, gb1)          # through relu(linear1(r))
+            ops.linear_bwd(r_in, self._aligned_weight(w1, refresh=False), h, gh, ACT_RELU, gr_in, gw1, gb1)  # relu(linear1(r))
             ops.act_bwd(r_out, gr, ACT_RELU, gr_in, accumulate=True)            # the skip connection
             gr = gr_in
             block_grads.append((gw1, gb1, gw2, gb2))

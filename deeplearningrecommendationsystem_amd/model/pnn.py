@@ -85,9 +85,9 @@ class PNN(FeatureModel):
         emb = torch.empty((batch, 6 * dim), dtype=torch.float32, device=x.device)
         ops.embed_fwd(six_field_specs(tables, dim), x, batch, emb, self._flag)
         if self.product.model == "in":
-            prod = ops.allpairs_fwd(emb, 6, dim)
+            prod = ops.allpairs_fwd(emb, 6, dim, out=self._padded_rows(batch, 15, x.device))
             lz = ops.linear_fwd(emb, w1, b1)
-            h0 = ops.linear_fwd(prod, w2, b2, residual=lz)
+            h0 = ops.linear_fwd(prod, self._aligned_weight(w2), b2, residual=lz)
             extra = (prod,)
         else:
             if batch != dim:
@@ -116,8 +116,8 @@ class PNN(FeatureModel):
         ops.linear_bwd(emb, w1, None, gh0, ACT_NONE, gemb, gw1, gb1)
         if self.product.model == "in":
             (prod,) = extra
-            gprod = torch.empty_like(prod)
-            ops.linear_bwd(prod, w2, None, gh0, ACT_NONE, gprod, gw2, gb2)
+            gprod = self._padded_rows(batch, 15, x.device)
+            ops.linear_bwd(prod, self._aligned_weight(w2, refresh=False), None, gh0, ACT_NONE, gprod, gw2, gb2)
             ops.allpairs_bwd(emb, 6, dim, gprod, gemb, accumulate=True)
         else:
             prod, s = extra
