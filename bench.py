@@ -120,6 +120,31 @@ def cpu_baseline(name: str, model, budget_s: float = 15.0):
             "ms_per_step": dt * 1e3}
 
 
+# kernel label (ops.py) -> kernel name in the rocprofv3 / PMC summaries under profiles/
+KERNEL_NAMES = {"mlp_fused_bwd": "mlp_bwd_kernel", "mlp_fused_fwd": "mlp_fwd_kernel", "embed_fwd": "embed_fwd_kernel",
+                "embed_bwd": "embed_bwd_kernel", "mf_fwd": "mf_fwd_kernel", "mf_bwd": "mf_bwd_kernel"}
+
+
+def pmc_traffic(workload, label):
+    """HBM bytes per launch of `label` from the newest committed PMC pass (dev/pmc_traffic.sh, FETCH_SIZE and
+    WRITE_SIZE collected in separate rocprofv3 passes).  FETCH_SIZE is doubled for the gfx950 wide-read
+    under-count only when that keeps the total <= 2x the raw reading; None when no pass is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_traffic.json")))
+    name = KERNEL_NAMES.get(label)
+    if not files or name is None:
+        return None
+    try:
+        table = json.load(open(files[-1]))
+    except (OSError, ValueError):
+        return None
+    for k, v in table.items():
+        if k.startswith(name):
+            return {"hbm_bytes_raw": v["hbm_bytes_raw"], "hbm_bytes_fetch_x2": v["hbm_bytes_fetchx2"],
+                    "source": os.path.relpath(files[-1], ROOT)}
+    return None
+
+
 def roofline_entry(label, rec):
     secs = rec["avg_us"] * 1e-6
     gbs = rec["bytes"] / secs / 1e9
@@ -255,8 +280,9 @@ def main():
             "config": {"workload": desc, "global_batch": world * batch_of(args.workload),
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "loss": float(loss.item()), "launch": "eager" if args.no_graph else "hipGraph replay",
-            "roofline": entries[dominant],
-            "gather_roofline": entries.get("embed_fwd"),
+            "roofline": dict(entries[dominant], traffic=pmc_traffic(args.workload, dominant)),
+            "gather_roofline": None if "embed_fwd" not in entries else
+            dict(entries["embed_fwd"], traffic=pmc_traffic(args.workload, "embed_fwd")),
             "kernels": {k: {"avg_us": round(v["avg_us"], 2), "calls_per_step": v["calls"] / args.steps,
                             "bound": entries[k]["bound"], "frac": round(entries[k]["frac"], 4)}
                         for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["total_us"])},
