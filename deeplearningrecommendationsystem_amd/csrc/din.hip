@@ -371,8 +371,10 @@ extern "C" int ctr_din_concat_bwd(const int64_t* hist, const int64_t* target, in
   if (batch == 0 || len == 0) return CTR_OK;
   CTR_REQUIRE(hist && target && gc && attn && gout && gtable && vocab > 0 && dim > 0, CTR_EINVAL);
   CTR_REQUIRE(ldc >= 3 * (int64_t)dim && ldgo >= dim && (!gt_extra || ldgt >= dim), CTR_EINVAL);
-  const bool al = ctr_aligned16(gc) && ldc % 4 == 0 && ctr_aligned16(gout) && ldgo % 4 == 0;
-  const SeqGeom g = make_geom(batch, len, dim, al);
+  // one dword per lane: a wave's atomic instruction then adds to contiguous runs of a gradient
+  // row (256 B for E >= 64), the shape that runs at the full memory-side atomic rate --
+  // dwordx4 per lane strides the lanes 16 B apart and measured 3x slower on the row scatter
+  const SeqGeom g = make_geom(batch, len, dim, false);
   int rc = check_dim(g);
   if (rc != CTR_OK) return rc;
   int grid = wave_grid(batch);

@@ -22,6 +22,9 @@
 // everything must fit LDS; otherwise CTR_ELIMIT and the caller uses the per-layer path.
 #include "ctr_common.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -56,6 +59,42 @@ struct StackDesc {
   int db_off[kMaxLayers];  // bwd: first bias-gradient slot of each layer
 };
 
+// Shape policy.  DynShape: every width comes from the descriptor at run time.  A fixed shape
+// pins n / k / activation of every layer at compile time for a stack that matters (the
+// BASELINE NeuralCF tower): the layer loops unroll, the index divisions, tail chunks and
+// range guards fold away -- the generic kernel spends ~3x its MFMA time issuing them.
+struct DynShape {
+  static constexpr bool kFixed = false;
+  static constexpr int kLayers = 0;
+  static constexpr int N[1] = {0};
+  static constexpr int K[1] = {0};
+  static constexpr int ACT[1] = {0};
+};
+struct NcfShape {  // model/neuralcf.py:23-27 at BASELINE configs[1]: 128 -> 64 -> 32 -> 16 -> 8 -> 64
+  static constexpr bool kFixed = true;
+  static constexpr int kLayers = 5;
+  static constexpr int N[5] = {64, 32, 16, 8, 64};
+  static constexpr int K[5] = {128, 64, 32, 16, 8};
+  static constexpr int ACT[5] = {CTR_ACT_RELU, CTR_ACT_RELU, CTR_ACT_RELU, CTR_ACT_RELU, CTR_ACT_NONE};
+};
+
+template <class F, int... I>
+__device__ __forceinline__ void static_layers(F& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+
+template <class S>
+__device__ __forceinline__ void pin_shape(LayerDesc& L, int li) {
+  if constexpr (S::kFixed) {
+    L.n = S::N[li];
+    L.k = S::K[li];
+    L.act = S::ACT[li];
+    int t = 0;
+    for (int j = 0; j < li; ++j) t += ((S::N[j] + 31) / 32) * ((S::K[j] + 31) / 32);
+    L.acc_off = t;
+  }
+}
+
 __device__ __forceinline__ int w_stride(int k) { return k + 4; }
 
 __device__ __forceinline__ void stage_weights(float* s_w, const StackDesc& d, bool with_bias) {
@@ -88,7 +127,7 @@ __device__ __forceinline__ void read_kc(const float* tile, int stride, int row, 
 // once per iteration) ----
 
 // [32][width] fp32 tile, width % 4 == 0, 16-byte aligned rows: src rows row0.. (zero past m)
-template <int U>
+template <int U, bool FIXED>
 __device__ __forceinline__ void tile_load4(float* tile, int stride, const float* __restrict__ src, int64_t ld,
                                            int64_t row0, int64_t m, int width, const CtrFastDiv& div_w4, int lane) {
   const int units = 8 * width;  // dwordx4 units in the tile
@@ -101,7 +140,7 @@ __device__ __forceinline__ void tile_load4(float* tile, int stride, const float*
       v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       off[u] = -1;
       if (i < units) {
-        const int rr = (int)ctr_div((uint32_t)i, div_w4), c = (i - rr * (width / 4)) * 4;
+        const int rr = FIXED ? i / (width / 4) : (int)ctr_div((uint32_t)i, div_w4), c = (i - rr * (width / 4)) * 4;
         off[u] = rr * stride + c;
         if (row0 + rr < m) v[u] = *reinterpret_cast<const float4*>(src + (row0 + rr) * ld + c);
       }
@@ -113,7 +152,7 @@ __device__ __forceinline__ void tile_load4(float* tile, int stride, const float*
 }
 
 // same for arbitrary width / alignment, one float per lane and load
-template <int U>
+template <int U, bool FIXED>
 __device__ __forceinline__ void tile_load1(float* tile, int stride, const float* __restrict__ src, int64_t ld,
                                            int64_t row0, int64_t m, int width, const CtrFastDiv& div_w, int lane) {
   const int units = 32 * width;
@@ -126,7 +165,7 @@ __device__ __forceinline__ void tile_load1(float* tile, int stride, const float*
       v[u] = 0.0f;
       off[u] = -1;
       if (i < units) {
-        const int rr = (int)ctr_div((uint32_t)i, div_w), c = i - rr * width;
+        const int rr = FIXED ? i / width : (int)ctr_div((uint32_t)i, div_w), c = i - rr * width;
         off[u] = rr * stride + c;
         if (row0 + rr < m) v[u] = src[(row0 + rr) * ld + c];
       }
@@ -138,7 +177,7 @@ __device__ __forceinline__ void tile_load1(float* tile, int stride, const float*
 }
 
 // tile[r][c] *= act'(y[row0+r][c]) for a [32][width] tile (rows past m are zero already)
-template <int U>
+template <int U, bool FIXED>
 __device__ __forceinline__ void tile_mask(float* tile, int stride, const float* __restrict__ y, int64_t ld,
                                           int64_t row0, int64_t m, int width, const CtrFastDiv& div_w, int act,
                                           int lane) {
@@ -152,7 +191,7 @@ __device__ __forceinline__ void tile_mask(float* tile, int stride, const float* 
       v[u] = 0.0f;
       off[u] = -1;
       if (i < units) {
-        const int rr = (int)ctr_div((uint32_t)i, div_w), c = i - rr * width;
+        const int rr = FIXED ? i / width : (int)ctr_div((uint32_t)i, div_w), c = i - rr * width;
         if (row0 + rr < m) {
           off[u] = rr * stride + c;
           v[u] = y[(row0 + rr) * ld + c];
@@ -187,6 +226,7 @@ __device__ __forceinline__ void fwd_chunk(const float* xt, int xstride, const fl
   }
 }
 
+template <class S>
 __global__ void __launch_bounds__(kThreads)
 mlp_fwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int64_t m) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -201,7 +241,7 @@ mlp_fwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // two wave-private tiles: layer l reads its input from one and writes its output to the
   // other, so outputs never wait for the last operand read of the same tile
-  const int sa = d.sa, sb = d.sb, nlayers = d.nlayers;
+  const int sa = d.sa, sb = d.sb, nlayers = S::kFixed ? S::kLayers : d.nlayers;
   float* ta = lds + d.wfloats + wave * 32 * (sa + sb);
   float* tb = ta + 32 * sa;
   const int r = lane & 31, h = lane >> 5;
@@ -209,7 +249,7 @@ mlp_fwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
   __syncthreads();
 
   const int64_t tiles = (m + 31) / 32;
-  const int k0 = d.l[0].k;
+  const int k0 = S::kFixed ? S::K[0] : d.l[0].k;
   // layer-0 input rows of a tile as dwordx4 units held in registers (k0 <= 128: <= 16 per
   // lane): the NEXT tile's rows are in flight while the current tile goes through the stack
   float4 pre[16];
@@ -222,7 +262,7 @@ mlp_fwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
       const int i = lane + 64 * u;
       pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i < units && tl < tiles) {
-        const int rr = (int)ctr_div((uint32_t)i, div0), c = (i - rr * (k0 / 4)) * 4;
+        const int rr = S::kFixed ? i / (k0 / 4) : (int)ctr_div((uint32_t)i, div0), c = (i - rr * (k0 / 4)) * 4;
         if (r0 + rr < m) pre[u] = *reinterpret_cast<const float4*>(x + (r0 + rr) * ldx + c);
       }
     }
@@ -235,26 +275,30 @@ mlp_fwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
     for (int u = 0; u < 16; ++u) {
       const int i = lane + 64 * u;
       if (i < units) {
-        const int rr = (int)ctr_div((uint32_t)i, div0), c = (i - rr * (k0 / 4)) * 4;
+        const int rr = S::kFixed ? i / (k0 / 4) : (int)ctr_div((uint32_t)i, div0), c = (i - rr * (k0 / 4)) * 4;
         *reinterpret_cast<float4*>(ta + rr * sa + c) = pre[u];
       }
     }
     fetch(tile + tstride);
     __builtin_amdgcn_wave_barrier();
+#pragma unroll
     for (int li = 0; li < nlayers; ++li) {
-      const LayerDesc L = d.l[li];  // by value: registers, not an LDS reload after every LDS store
+      LayerDesc L = d.l[li];  // by value: registers, not an LDS reload after every LDS store
+      pin_shape<S>(L, li);
       const float* wl = s_w + L.w_off;
       const int ws = w_stride(L.k);
       const int nct = (L.n + 31) / 32;
       const float* xin = (li & 1) ? tb : ta;
       float* xout = (li & 1) ? ta : tb;
       const int sin = (li & 1) ? sb : sa, sout = (li & 1) ? sa : sb;
+#pragma unroll
       for (int ct = 0; ct < nct; ++ct) {
         floatx16 a, a1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) a[e] = a1[e] = 0.0f;
         const int j = 32 * ct + r;
         int base = 0;
+#pragma unroll
         for (; base + 32 <= L.k; base += 32) fwd_chunk<16>(xin, sin, wl, ws, L.n, j, base, r, h, a, a1);
         const int rem = L.k - base;  // 0, 8, 16 or 24
         if (rem == 8) fwd_chunk<4>(xin, sin, wl, ws, L.n, j, base, r, h, a, a1);
@@ -311,7 +355,7 @@ __device__ __forceinline__ void dx_chunk(const float* gt, int gstride, const flo
   }
 }
 
-template <int MAXT>
+template <class S, int MAXT>
 __global__ void __launch_bounds__(kThreads)
 mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int64_t m, const float* __restrict__ gy,
                int64_t ldgy, float* __restrict__ gx, int64_t ldgx, float* __restrict__ ws, int64_t slab) {
@@ -322,7 +366,7 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
   __syncthreads();
   const StackDesc& d = s_desc;
   float* s_w = lds;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // two wave-private tiles P (stride sa) and Q (stride sb).  Walking the layers from the
   // last one, the gradient tile and the layer-input tile swap every layer: dX_l is written
   // over X_l (dW_l has consumed it) and is the gY of layer l-1, whose input then goes
@@ -330,7 +374,6 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
   const int sa = d.sa, sb = d.sb;
   float* tp = lds + d.wfloats + wave * 32 * (sa + sb);
   float* tq = tp + 32 * sa;
-  const int r = lane & 31, h = lane >> 5;
   stage_weights(s_w, d, false);
   __syncthreads();
 
@@ -341,27 +384,38 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
     for (int e = 0; e < 16; ++e) dw[t][e] = 0.0f;
   // bias-gradient partials: nsum floats per wave in LDS (lane j owns column j of each layer)
   float* s_db = lds + d.wfloats + kWaves * 32 * (sa + sb) + wave * d.nsum;
-  for (int i = lane; i < d.nsum; i += 64) s_db[i] = 0.0f;
+  for (int i = lane0; i < d.nsum; i += 64) s_db[i] = 0.0f;
 
   const int64_t tiles = (m + 31) / 32;
-  const int last = d.nlayers - 1;
+  const int nlayers = S::kFixed ? S::kLayers : d.nlayers;
+  const int last = nlayers - 1;
   const CtrFastDiv div_last = d.l[last].div_n;
-  const int nl = d.l[last].n;
+  const int nl = S::kFixed ? S::N[S::kFixed ? S::kLayers - 1 : 0] : d.l[last].n;
   for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += (int64_t)gridDim.x * kWaves) {
     const int64_t row0 = tile * 32;
+    // fixed shape: every lane-derived LDS / global offset of the unrolled stack is loop
+    // invariant, and hoisting those few hundred values out of the tile loop spills them.
+    // Re-deriving them per tile costs a shift and an add each.
+    int lane = lane0;
+    if constexpr (S::kFixed) asm volatile("" : "+v"(lane));
+    const int r = lane & 31, h = lane >> 5;
     // gradient of the last layer's output -> P
-    tile_load1<8>(tp, sa, gy, ldgy, row0, m, nl, div_last, lane);
+    tile_load1<8, S::kFixed>(tp, sa, gy, ldgy, row0, m, nl, div_last, lane);
     __builtin_amdgcn_wave_barrier();
-    for (int li = last; li >= 0; --li) {
+    // one layer of the backward walk; lqv is an int (DynShape) or an integral_constant
+    // (fixed shape: one instantiation per layer, everything shape-dependent folds)
+    auto layer = [&](auto lqv) __attribute__((always_inline)) {
+      const int li = last - (int)lqv;
       {
-        const LayerDesc L = d.l[li];  // by value: registers, not an LDS reload after every LDS store
+        LayerDesc L = d.l[li];  // by value: registers, not an LDS reload after every LDS store
+        pin_shape<S>(L, li);
         const int dboff = d.db_off[li];
         const bool even = ((last - li) & 1) == 0;
         float* gt = even ? tp : tq;      // gY -> gZ of this layer
         float* xt = even ? tq : tp;      // X_l, then dX_l
         const int gs = even ? sa : sb, xs = even ? sb : sa;
         // gZ = gY * act'(Y) in place (rows past m stay zero)
-        if (L.act != CTR_ACT_NONE) tile_mask<8>(gt, gs, L.y, L.ldy, row0, m, L.n, L.div_n, L.act, lane);
+        if (L.act != CTR_ACT_NONE) tile_mask<8, S::kFixed>(gt, gs, L.y, L.ldy, row0, m, L.n, L.div_n, L.act, lane);
         {
           // zero the columns [n, round_up(n, 8)) the last dX chunk will read
           const int npad = (L.n + 7) / 8 * 8 - L.n;
@@ -377,7 +431,7 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
           src = d.l[li > 0 ? li - 1 : 0].y;
           ld_in = d.l[li > 0 ? li - 1 : 0].ldy;
         }
-        tile_load4<4>(xt, xs, src, ld_in, row0, m, L.k, L.div_k4, lane);
+        tile_load4<4, S::kFixed>(xt, xs, src, ld_in, row0, m, L.k, L.div_k4, lane);
         __builtin_amdgcn_wave_barrier();
         // bias gradient: lane j sums column j of gZ over the 32 rows
 #pragma unroll
@@ -444,12 +498,14 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
           const float* wl = s_w + L.w_off;
           const int wsd = w_stride(L.k);
           const int nkt = (L.k + 31) / 32;
+#pragma unroll
           for (int ct = 0; ct < nkt; ++ct) {
             floatx16 a, a1;
 #pragma unroll
             for (int e = 0; e < 16; ++e) a[e] = a1[e] = 0.0f;
             const int col = 32 * ct + r;
             int base = 0;
+#pragma unroll
             for (; base + 32 <= L.n; base += 32) dx_chunk<16>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a, a1);
             const int rem = L.n - base;  // 0..31, the tile is zero-padded to a multiple of 8
             if (rem > 24) dx_chunk<16>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a, a1);
@@ -473,10 +529,16 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
           __builtin_amdgcn_wave_barrier();
         }
       }
+    };
+    if constexpr (S::kFixed) {
+      static_layers(layer, std::make_integer_sequence<int, S::kLayers>{});
+    } else {
+      for (int lq = 0; lq < nlayers; ++lq) layer(lq);
     }
   }
 
   // workgroup partial of dW / db: the 4 waves add theirs in LDS, then one slab in the workspace
+  const int lane = lane0, r = lane0 & 31, h = lane0 >> 5;
   __syncthreads();
   float* s_red = lds + d.wfloats;  // reuse the activation tiles: nothing reads them any more
   const float* s_dbv = lds + d.wfloats + kWaves * 32 * (sa + sb);  // the waves' bias partials, kept beyond the tiles
@@ -596,6 +658,14 @@ int build(const ctr_mlp_layer_t* layers, int nlayers, bool backward, Built* out)
   return CTR_OK;
 }
 
+template <class S>
+bool matches(const ctr_mlp_layer_t* layers, int nlayers) {
+  if (!S::kFixed || nlayers != S::kLayers) return false;
+  for (int i = 0; i < nlayers; ++i)
+    if (layers[i].n != S::N[i] || layers[i].k != S::K[i] || layers[i].act != S::ACT[i]) return false;
+  return true;
+}
+
 template <class K>
 int allow_lds(K kernel, size_t bytes) {
   if (bytes <= 48 * 1024) return CTR_OK;
@@ -616,13 +686,20 @@ extern "C" int ctr_mlp_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp
   int rc = build(layers, nlayers, false, &b);
   if (rc != CTR_OK) return rc;
   CTR_REQUIRE(ldx >= b.d.l[0].k, CTR_EINVAL);
-  rc = allow_lds(mlp_fwd_kernel, b.lds_bytes);
-  if (rc != CTR_OK) return rc;
   const int64_t tiles = ctr_ceil_div(m, 32);
   int64_t grid = ctr_ceil_div(tiles, kWaves);
   if (grid > 256) grid = 256;  // persistent: one workgroup per CU, weights staged once
-  hipLaunchKernelGGL(mlp_fwd_kernel, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, (hipStream_t)stream, b.d, x, ldx,
-                     m);
+  if (matches<NcfShape>(layers, nlayers)) {
+    rc = allow_lds(mlp_fwd_kernel<NcfShape>, b.lds_bytes);
+    if (rc != CTR_OK) return rc;
+    hipLaunchKernelGGL(mlp_fwd_kernel<NcfShape>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, (hipStream_t)stream,
+                       b.d, x, ldx, m);
+  } else {
+    rc = allow_lds(mlp_fwd_kernel<DynShape>, b.lds_bytes);
+    if (rc != CTR_OK) return rc;
+    hipLaunchKernelGGL(mlp_fwd_kernel<DynShape>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, (hipStream_t)stream,
+                       b.d, x, ldx, m);
+  }
   return ctr_launch_status();
 }
 
@@ -644,17 +721,18 @@ extern "C" int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp
   if (grid > 256) grid = 256;
   CTR_REQUIRE(workspace_floats >= grid * b.slab, CTR_ELIMIT);
   hipStream_t st = (hipStream_t)stream;
-#define CTR_LAUNCH_BWD(T)                                                                                          \
+#define CTR_LAUNCH_BWD(S, T)                                                                                       \
   do {                                                                                                             \
-    rc = allow_lds(mlp_bwd_kernel<T>, b.lds_bytes);                                                                \
+    rc = allow_lds(mlp_bwd_kernel<S, T>, b.lds_bytes);                                                             \
     if (rc != CTR_OK) return rc;                                                                                   \
-    hipLaunchKernelGGL(mlp_bwd_kernel<T>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, st, b.d, x, ldx, m, gy, \
-                       ldgy, gx, ldgx, workspace, b.slab);                                                         \
+    hipLaunchKernelGGL((mlp_bwd_kernel<S, T>), dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, st, b.d, x, ldx, \
+                       m, gy, ldgy, gx, ldgx, workspace, b.slab);                                                  \
   } while (0)
-  if (maxt == 8) CTR_LAUNCH_BWD(8);
-  else if (maxt == 12) CTR_LAUNCH_BWD(12);
-  else if (maxt == 14) CTR_LAUNCH_BWD(14);
-  else CTR_LAUNCH_BWD(16);
+  if (matches<NcfShape>(layers, nlayers)) CTR_LAUNCH_BWD(NcfShape, 14);
+  else if (maxt == 8) CTR_LAUNCH_BWD(DynShape, 8);
+  else if (maxt == 12) CTR_LAUNCH_BWD(DynShape, 12);
+  else if (maxt == 14) CTR_LAUNCH_BWD(DynShape, 14);
+  else CTR_LAUNCH_BWD(DynShape, 16);
 #undef CTR_LAUNCH_BWD
   rc = ctr_launch_status();
   if (rc != CTR_OK) return rc;
