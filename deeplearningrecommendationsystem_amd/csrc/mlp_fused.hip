@@ -83,19 +83,80 @@ __device__ __forceinline__ void static_layers(F& f, std::integer_sequence<int, I
   (f(std::integral_constant<int, I>{}), ...);
 }
 
-template <class S>
+// LDS layout of a stack as compile-time functions of a fixed shape (the host's build()
+// computes the same numbers at run time and refuses the instantiation if they differ).
+// With strides and offsets pinned, LDS addresses are one base register + immediates; left
+// as run-time values the compiler materialised ~30 row addresses per tile, hoisted them out
+// of the tile loop and spilled them (a serialised scratch reload costs ~700 cycles here).
+template <class S, bool BWD>
+struct Layout {
+  static constexpr int r8(int v) { return (v + 7) / 8 * 8; }
+  static constexpr int w_off(int li) {
+    int o = 0;
+    for (int j = 0; j < li; ++j) o += r8(S::N[j]) * (S::K[j] + 4) + (S::N[j] + 3) / 4 * 4;
+    return o;
+  }
+  static constexpr int b_off(int li) { return w_off(li) + r8(S::N[li]) * (S::K[li] + 4); }
+  static constexpr int wfloats() { return (w_off(S::kLayers) + 3) / 4 * 4; }
+  static constexpr int acc_off(int li) {
+    int t = 0;
+    for (int j = 0; j < li; ++j) t += ((S::N[j] + 31) / 32) * ((S::K[j] + 31) / 32);
+    return t;
+  }
+  static constexpr int db_off(int li) {
+    int t = 0;
+    for (int j = 0; j < li; ++j) t += S::N[j];
+    return t;
+  }
+  static constexpr int nsum() { return db_off(S::kLayers); }
+  // widths of the two swapping tiles (see build())
+  static constexpr int width(bool first) {
+    int wa = 0, wb = 0;
+    for (int i = 0; i < S::kLayers; ++i) {
+      if (BWD) {
+        const bool even = ((S::kLayers - 1 - i) & 1) == 0;
+        const int n8 = r8(S::N[i]);
+        if (even) {
+          wa = n8 > wa ? n8 : wa;
+          wb = S::K[i] > wb ? S::K[i] : wb;
+        } else {
+          wb = n8 > wb ? n8 : wb;
+          wa = S::K[i] > wa ? S::K[i] : wa;
+        }
+      } else {
+        if (i & 1) {
+          wb = S::K[i] > wb ? S::K[i] : wb;
+          wa = S::N[i] > wa ? S::N[i] : wa;
+        } else {
+          wa = S::K[i] > wa ? S::K[i] : wa;
+          wb = S::N[i] > wb ? S::N[i] : wb;
+        }
+      }
+    }
+    return first ? wa : wb;
+  }
+  static constexpr int sa() { return width(true) + 4; }
+  static constexpr int sb() { return width(false) + 4; }
+};
+
+template <class S, bool BWD>
 __device__ __forceinline__ void pin_shape(LayerDesc& L, int li) {
   if constexpr (S::kFixed) {
+    using Y = Layout<S, BWD>;
     L.n = S::N[li];
     L.k = S::K[li];
     L.act = S::ACT[li];
-    int t = 0;
-    for (int j = 0; j < li; ++j) t += ((S::N[j] + 31) / 32) * ((S::K[j] + 31) / 32);
-    L.acc_off = t;
+    L.w_off = Y::w_off(li);
+    L.b_off = Y::b_off(li);
+    L.acc_off = Y::acc_off(li);
   }
 }
 
 __device__ __forceinline__ int w_stride(int k) { return k + 4; }
+// unguarded fragment reads of a column tile wider than the layer run < 32 floats past the
+// end of a tile; weight rows past a layer land in the biases / tiles that follow.  Keep the
+// former inside the allocation.
+constexpr int kSlack = 32;
 
 __device__ __forceinline__ void stage_weights(float* s_w, const StackDesc& d, bool with_bias) {
   for (int li = 0; li < d.nlayers; ++li) {
@@ -104,9 +165,14 @@ __device__ __forceinline__ void stage_weights(float* s_w, const StackDesc& d, bo
       for (int i = threadIdx.x; i < L.n; i += blockDim.x) s_w[L.b_off + i] = L.b ? L.b[i] : 0.0f;
     float* dst = s_w + L.w_off;
     const int ws = w_stride(L.k);
-    for (int i = threadIdx.x * 4; i < L.n * L.k; i += blockDim.x * 4) {
-      const int r = i / L.k, c = i - r * L.k;  // k % 4 == 0: a float4 never crosses a row
-      *reinterpret_cast<float4*>(dst + r * ws + c) = *reinterpret_cast<const float4*>(L.w + i);
+    // rows [n, round_up(n, 8)) are staged as zeros: the contraction chunks of dX run over
+    // multiples of 8 and need no per-element range check
+    const int units = (L.n + 7) / 8 * 8 * (L.k / 4);  // k % 4 == 0: a float4 never crosses a row
+    for (int u = threadIdx.x; u < units; u += blockDim.x) {
+      const int r = (int)ctr_div((uint32_t)u, L.div_k4), c = (u - r * (L.k / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < L.n) v = *reinterpret_cast<const float4*>(L.w + (int64_t)r * L.k + c);
+      *reinterpret_cast<float4*>(dst + r * ws + c) = v;
     }
   }
 }
@@ -148,6 +214,39 @@ __device__ __forceinline__ void tile_load4(float* tile, int stride, const float*
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (off[u] >= 0) *reinterpret_cast<float4*>(tile + off[u]) = v[u];
+  }
+}
+
+// the same tile in two halves: pre_issue puts the loads in flight into registers (<= 16
+// dwordx4 per lane for width <= 128), pre_commit parks them in LDS once they are needed
+template <bool FIXED>
+__device__ __forceinline__ void pre_issue(float4 (&pre)[16], const float* __restrict__ src, int64_t ld, int64_t row0,
+                                          int64_t m, int width, const CtrFastDiv& div_w4, int lane, bool live) {
+  const int units = 8 * width;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int i = lane + 64 * u;
+    pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live && i < units) {
+      const int rr = FIXED ? i / (width / 4) : (int)ctr_div((uint32_t)i, div_w4), c = (i - rr * (width / 4)) * 4;
+      // clamped address + select instead of a branch per load
+      const int64_t row = row0 + rr < m ? row0 + rr : m - 1;
+      const float4 v = *reinterpret_cast<const float4*>(src + row * ld + c);
+      if (row0 + rr < m) pre[u] = v;
+    }
+  }
+}
+template <bool FIXED>
+__device__ __forceinline__ void pre_commit(const float4 (&pre)[16], float* tile, int stride, int width,
+                                           const CtrFastDiv& div_w4, int lane) {
+  const int units = 8 * width;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int i = lane + 64 * u;
+    if (i < units) {
+      const int rr = FIXED ? i / (width / 4) : (int)ctr_div((uint32_t)i, div_w4), c = (i - rr * (width / 4)) * 4;
+      *reinterpret_cast<float4*>(tile + rr * stride + c) = pre[u];
+    }
   }
 }
 
@@ -209,16 +308,13 @@ __device__ __forceinline__ void tile_mask(float* tile, int stride, const float* 
 // (two accumulator chains, even / odd steps: a dependent chain of this MFMA runs at ~0.4x
 // its issue rate and a wave is alone on its SIMD here)
 template <int STEPS>
-__device__ __forceinline__ void fwd_chunk(const float* xt, int xstride, const float* wl, int wstride, int n, int j,
-                                          int base, int r, int h, floatx16& acc0, floatx16& acc1) {
+__device__ __forceinline__ void fwd_chunk(const float* xt, int xstride, const float* wl, int wstride, int j, int base,
+                                          int r, int h, floatx16& acc0, floatx16& acc1) {
   float fa[16], fb[16];
   read_kc<STEPS>(xt, xstride, r, base, h, fa);
-  if (j < n) {
-    read_kc<STEPS>(wl, wstride, j, base, h, fb);
-  } else {
-#pragma unroll
-    for (int t = 0; t < STEPS; ++t) fb[t] = 0.0f;
-  }
+  // lanes with j >= n read whatever follows the layer's rows in LDS: their output columns
+  // are never stored, and a branch here would split every chunk into basic blocks
+  read_kc<STEPS>(wl, wstride, j, base, h, fb);
 #pragma unroll
   for (int t = 0; t < STEPS; t += 2) {
     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc0, 0, 0, 0);
@@ -238,11 +334,13 @@ mlp_fwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
   __syncthreads();
   const StackDesc& d = s_desc;
   float* s_w = lds;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // two wave-private tiles: layer l reads its input from one and writes its output to the
   // other, so outputs never wait for the last operand read of the same tile
-  const int sa = d.sa, sb = d.sb, nlayers = S::kFixed ? S::kLayers : d.nlayers;
-  float* ta = lds + d.wfloats + wave * 32 * (sa + sb);
+  using Y = Layout<S, false>;
+  const int sa = S::kFixed ? Y::sa() : d.sa, sb = S::kFixed ? Y::sb() : d.sb;
+  const int nlayers = S::kFixed ? S::kLayers : d.nlayers, wfloats = S::kFixed ? Y::wfloats() : d.wfloats;
+  float* ta = lds + wfloats + wave * 32 * (sa + sb);
   float* tb = ta + 32 * sa;
   const int r = lane & 31, h = lane >> 5;
   stage_weights(s_w, d, true);
@@ -284,7 +382,7 @@ mlp_fwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
 #pragma unroll
     for (int li = 0; li < nlayers; ++li) {
       LayerDesc L = d.l[li];  // by value: registers, not an LDS reload after every LDS store
-      pin_shape<S>(L, li);
+      pin_shape<S, false>(L, li);
       const float* wl = s_w + L.w_off;
       const int ws = w_stride(L.k);
       const int nct = (L.n + 31) / 32;
@@ -299,21 +397,28 @@ mlp_fwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
         const int j = 32 * ct + r;
         int base = 0;
 #pragma unroll
-        for (; base + 32 <= L.k; base += 32) fwd_chunk<16>(xin, sin, wl, ws, L.n, j, base, r, h, a, a1);
+        for (; base + 32 <= L.k; base += 32) fwd_chunk<16>(xin, sin, wl, ws, j, base, r, h, a, a1);
         const int rem = L.k - base;  // 0, 8, 16 or 24
-        if (rem == 8) fwd_chunk<4>(xin, sin, wl, ws, L.n, j, base, r, h, a, a1);
-        else if (rem == 16) fwd_chunk<8>(xin, sin, wl, ws, L.n, j, base, r, h, a, a1);
-        else if (rem == 24) fwd_chunk<12>(xin, sin, wl, ws, L.n, j, base, r, h, a, a1);
+        if (rem == 8) fwd_chunk<4>(xin, sin, wl, ws, j, base, r, h, a, a1);
+        else if (rem == 16) fwd_chunk<8>(xin, sin, wl, ws, j, base, r, h, a, a1);
+        else if (rem == 24) fwd_chunk<12>(xin, sin, wl, ws, j, base, r, h, a, a1);
 #pragma unroll
         for (int e = 0; e < 16; ++e) a[e] += a1[e];
         if (j < L.n) {
           const float bias = s_w[L.b_off + j];
+          float* yp = L.y + (row0 + 4 * h) * L.ldy + j;
+          float* xo = xout + 4 * h * sout + j;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-            const float v = ctr_act(a[e] + bias, L.act);
-            xout[row * sout + j] = v;
-            if (row0 + row < m) ctr_stg(L.y + (row0 + row) * L.ldy + j, v);
+          for (int e = 0; e < 16; ++e) a[e] = ctr_act(a[e] + bias, L.act);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) xo[((e & 3) + 8 * (e >> 2)) * sout] = a[e];
+          if (row0 + 32 <= m) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ctr_stg(yp + ((e & 3) + 8 * (e >> 2)) * L.ldy, a[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              if (row0 + (e & 3) + 8 * (e >> 2) + 4 * h < m) ctr_stg(yp + ((e & 3) + 8 * (e >> 2)) * L.ldy, a[e]);
           }
         }
       }
@@ -334,20 +439,14 @@ __device__ __forceinline__ void read_ks(const float* tile, int stride, int col, 
 // n need not be a multiple of 8: the gZ tile is zero-padded to the chunk width and weight
 // rows >= n read as zero.
 template <int STEPS>
-__device__ __forceinline__ void dx_chunk(const float* gt, int gstride, const float* wl, int wstride, int n, int k,
-                                         int col, int base, int r, int h, floatx16& acc0, floatx16& acc1) {
+__device__ __forceinline__ void dx_chunk(const float* gt, int gstride, const float* wl, int wstride, int col, int base,
+                                         int r, int h, floatx16& acc0, floatx16& acc1) {
   float fa[16], fb[16];
   read_kc<STEPS>(gt, gstride, r, base, h, fa);
-  if (col < k) {
+  // one base address + immediate offsets; lanes with col >= k feed columns nobody stores
+  const float* wp = wl + (base + STEPS * h) * wstride + col;
 #pragma unroll
-    for (int t = 0; t < STEPS; ++t) {
-      const int nn = base + STEPS * h + t;
-      fb[t] = nn < n ? wl[nn * wstride + col] : 0.0f;
-    }
-  } else {
-#pragma unroll
-    for (int t = 0; t < STEPS; ++t) fb[t] = 0.0f;
-  }
+  for (int t = 0; t < STEPS; ++t) fb[t] = wp[t * wstride];
 #pragma unroll
   for (int t = 0; t < STEPS; t += 2) {
     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc0, 0, 0, 0);
@@ -361,21 +460,32 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
                int64_t ldgy, float* __restrict__ gx, int64_t ldgx, float* __restrict__ ws, int64_t slab) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ StackDesc s_desc;  // see mlp_fwd_kernel
+#ifdef CTR_MLP_TIMING
+  uint64_t stamps[16];
+  int nstamp = 0;
+#define CTR_STAMP() do { if (nstamp < 16) stamps[nstamp++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CTR_STAMP() do {} while (0)
+#endif
+  CTR_STAMP();
   for (int i = threadIdx.x; i < (int)(sizeof(StackDesc) / 4); i += blockDim.x)
     reinterpret_cast<uint32_t*>(&s_desc)[i] = reinterpret_cast<const uint32_t*>(&dk)[i];
   __syncthreads();
   const StackDesc& d = s_desc;
   float* s_w = lds;
-  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // two wave-private tiles P (stride sa) and Q (stride sb).  Walking the layers from the
   // last one, the gradient tile and the layer-input tile swap every layer: dX_l is written
   // over X_l (dW_l has consumed it) and is the gY of layer l-1, whose input then goes
   // where gZ_l was.
-  const int sa = d.sa, sb = d.sb;
-  float* tp = lds + d.wfloats + wave * 32 * (sa + sb);
+  using Y = Layout<S, true>;
+  const int sa = S::kFixed ? Y::sa() : d.sa, sb = S::kFixed ? Y::sb() : d.sb;
+  const int wfloats = S::kFixed ? Y::wfloats() : d.wfloats, nsum = S::kFixed ? Y::nsum() : d.nsum;
+  float* tp = lds + wfloats + wave * 32 * (sa + sb);
   float* tq = tp + 32 * sa;
   stage_weights(s_w, d, false);
   __syncthreads();
+  CTR_STAMP();
 
   floatx16 dw[MAXT];  // dW accumulator tiles of every layer, alive across all row tiles
 #pragma unroll
@@ -383,39 +493,58 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
 #pragma unroll
     for (int e = 0; e < 16; ++e) dw[t][e] = 0.0f;
   // bias-gradient partials: nsum floats per wave in LDS (lane j owns column j of each layer)
-  float* s_db = lds + d.wfloats + kWaves * 32 * (sa + sb) + wave * d.nsum;
-  for (int i = lane0; i < d.nsum; i += 64) s_db[i] = 0.0f;
+  float* s_db = lds + wfloats + kWaves * 32 * (sa + sb) + wave * nsum;
+  for (int i = lane0; i < nsum; i += 64) s_db[i] = 0.0f;
 
   const int64_t tiles = (m + 31) / 32;
   const int nlayers = S::kFixed ? S::kLayers : d.nlayers;
   const int last = nlayers - 1;
   const CtrFastDiv div_last = d.l[last].div_n;
   const int nl = S::kFixed ? S::N[S::kFixed ? S::kLayers - 1 : 0] : d.l[last].n;
-  for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += (int64_t)gridDim.x * kWaves) {
+  constexpr bool kPre = S::kFixed;
+  const int64_t tstride = (int64_t)gridDim.x * kWaves;
+  float4 pre[16];  // kPre: the next layer-input tile, in flight
+  const float* xlast = last > 0 ? d.l[last > 0 ? last - 1 : 0].y : x;
+  const int64_t ldxlast = last > 0 ? d.l[last > 0 ? last - 1 : 0].ldy : ldx;
+  if constexpr (kPre) {
+    const int64_t t0 = (int64_t)blockIdx.x * kWaves + wave;
+    pre_issue<true>(pre, xlast, ldxlast, t0 * 32, m, S::K[S::kFixed ? S::kLayers - 1 : 0], d.l[last].div_k4, lane0,
+                    t0 < tiles);
+  }
+  for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += tstride) {
     const int64_t row0 = tile * 32;
     // fixed shape: every lane-derived LDS / global offset of the unrolled stack is loop
     // invariant, and hoisting those few hundred values out of the tile loop spills them.
     // Re-deriving them per tile costs a shift and an add each.
+    const bool full = row0 + 32 <= m;
     int lane = lane0;
     if constexpr (S::kFixed) asm volatile("" : "+v"(lane));
     const int r = lane & 31, h = lane >> 5;
     // gradient of the last layer's output -> P
     tile_load1<8, S::kFixed>(tp, sa, gy, ldgy, row0, m, nl, div_last, lane);
     __builtin_amdgcn_wave_barrier();
+    {
+      // gZ = gY * act'(Y) of the last layer, in place (rows past m stay zero)
+      const int act_last = S::kFixed ? S::ACT[S::kFixed ? S::kLayers - 1 : 0] : d.l[last].act;
+      if (act_last != CTR_ACT_NONE) {
+        tile_mask<8, S::kFixed>(tp, sa, d.l[last].y, d.l[last].ldy, row0, m, nl, div_last, act_last, lane);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
     // one layer of the backward walk; lqv is an int (DynShape) or an integral_constant
     // (fixed shape: one instantiation per layer, everything shape-dependent folds)
     auto layer = [&](auto lqv) __attribute__((always_inline)) {
       const int li = last - (int)lqv;
       {
         LayerDesc L = d.l[li];  // by value: registers, not an LDS reload after every LDS store
-        pin_shape<S>(L, li);
-        const int dboff = d.db_off[li];
+        pin_shape<S, true>(L, li);
+        const int dboff = S::kFixed ? Y::db_off(S::kFixed ? li : 0) : d.db_off[li];
         const bool even = ((last - li) & 1) == 0;
         float* gt = even ? tp : tq;      // gY -> gZ of this layer
         float* xt = even ? tq : tp;      // X_l, then dX_l
         const int gs = even ? sa : sb, xs = even ? sb : sa;
-        // gZ = gY * act'(Y) in place (rows past m stay zero)
-        if (L.act != CTR_ACT_NONE) tile_mask<8, S::kFixed>(gt, gs, L.y, L.ldy, row0, m, L.n, L.div_n, L.act, lane);
+        // gt holds gZ_l already: the last layer's gY was masked on load, every other one
+        // by the dX write-back of the layer above
         {
           // zero the columns [n, round_up(n, 8)) the last dX chunk will read
           const int npad = (L.n + 7) / 8 * 8 - L.n;
@@ -431,7 +560,23 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
           src = d.l[li > 0 ? li - 1 : 0].y;
           ld_in = d.l[li > 0 ? li - 1 : 0].ldy;
         }
-        tile_load4<4, S::kFixed>(xt, xs, src, ld_in, row0, m, L.k, L.div_k4, lane);
+        if constexpr (kPre) {
+          // X_l was requested one layer (or one tile) ago; park it, then request the next
+          // operand so its HBM latency runs under this layer's MFMAs
+          pre_commit<true>(pre, xt, xs, L.k, L.div_k4, lane);
+          if (li > 0) {
+            const int lp = li > 0 ? li - 1 : 0;
+            const float* nsrc = lp > 0 ? d.l[lp > 0 ? lp - 1 : 0].y : x;
+            const int64_t nld = lp > 0 ? d.l[lp > 0 ? lp - 1 : 0].ldy : ldx;
+            pre_issue<true>(pre, nsrc, nld, row0, m, S::K[S::kFixed ? lp : 0], d.l[lp].div_k4, lane, true);
+          } else {
+            const int64_t nt = tile + tstride;
+            pre_issue<true>(pre, xlast, ldxlast, nt * 32, m, S::K[S::kFixed ? S::kLayers - 1 : 0], d.l[last].div_k4, lane,
+                            nt < tiles);
+          }
+        } else {
+          tile_load4<4, S::kFixed>(xt, xs, src, ld_in, row0, m, L.k, L.div_k4, lane);
+        }
         __builtin_amdgcn_wave_barrier();
         // bias gradient: lane j sums column j of gZ over the 32 rows
 #pragma unroll
@@ -443,6 +588,7 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
             s_db[dboff + j] += t;
           }
         }
+        CTR_STAMP();
         // dW_l[n][k] += sum_rows gZ[row][n] X[row][k]: contraction = the 32 rows, 16 steps.
         // The accumulator index must be a compile-time constant (a run-time index would
         // send the tiles to scratch), so walk every slot and take this layer's ones.
@@ -459,29 +605,27 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
               {
                 const int it = okA ? relA / nkt : 0, jt = okA ? relA - it * nkt : 0;
                 const int ncol = 32 * it + r, kcol = 32 * jt + r;
-                if (okA && ncol < L.n) read_ks<16>(gt, gs, ncol, 0, h, faA);
-                else {
+                // columns past n / k read their neighbours in LDS and land in dW elements
+                // that the flush drops; only a slot of another layer must add nothing
+                if (okA) {
+                  read_ks<16>(gt, gs, ncol, 0, h, faA);
+                  read_ks<16>(xt, xs, kcol, 0, h, fbA);
+                } else {
 #pragma unroll
-                  for (int t = 0; t < 16; ++t) faA[t] = 0.0f;
-                }
-                if (okA && kcol < L.k) read_ks<16>(xt, xs, kcol, 0, h, fbA);
-                else {
-#pragma unroll
-                  for (int t = 0; t < 16; ++t) fbA[t] = 0.0f;
+                  for (int t = 0; t < 16; ++t) faA[t] = fbA[t] = 0.0f;
                 }
               }
               {
                 const int it = okB ? relB / nkt : 0, jt = okB ? relB - it * nkt : 0;
                 const int ncol = 32 * it + r, kcol = 32 * jt + r;
-                if (okB && ncol < L.n) read_ks<16>(gt, gs, ncol, 0, h, faB);
-                else {
+                // columns past n / k read their neighbours in LDS and land in dW elements
+                // that the flush drops; only a slot of another layer must add nothing
+                if (okB) {
+                  read_ks<16>(gt, gs, ncol, 0, h, faB);
+                  read_ks<16>(xt, xs, kcol, 0, h, fbB);
+                } else {
 #pragma unroll
-                  for (int t = 0; t < 16; ++t) faB[t] = 0.0f;
-                }
-                if (okB && kcol < L.k) read_ks<16>(xt, xs, kcol, 0, h, fbB);
-                else {
-#pragma unroll
-                  for (int t = 0; t < 16; ++t) fbB[t] = 0.0f;
+                  for (int t = 0; t < 16; ++t) faB[t] = fbB[t] = 0.0f;
                 }
               }
 #pragma unroll
@@ -493,11 +637,14 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
           }
         }
         __builtin_amdgcn_wave_barrier();
+        CTR_STAMP();
         // dX_l = gZ W_l (32 x k): over X_l in LDS (the next layer's gY) or, for layer 0, to HBM
         {
           const float* wl = s_w + L.w_off;
           const int wsd = w_stride(L.k);
           const int nkt = (L.k + 31) / 32;
+          int act_prev = CTR_ACT_NONE;
+          if (li > 0) act_prev = S::kFixed ? S::ACT[S::kFixed && li > 0 ? li - 1 : 0] : d.l[li > 0 ? li - 1 : 0].act;
 #pragma unroll
           for (int ct = 0; ct < nkt; ++ct) {
             floatx16 a, a1;
@@ -506,23 +653,43 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
             const int col = 32 * ct + r;
             int base = 0;
 #pragma unroll
-            for (; base + 32 <= L.n; base += 32) dx_chunk<16>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a, a1);
+            for (; base + 32 <= L.n; base += 32) dx_chunk<16>(gt, gs, wl, wsd, col, base, r, h, a, a1);
             const int rem = L.n - base;  // 0..31, the tile is zero-padded to a multiple of 8
-            if (rem > 24) dx_chunk<16>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a, a1);
-            else if (rem > 16) dx_chunk<12>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a, a1);
-            else if (rem > 8) dx_chunk<8>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a, a1);
-            else if (rem > 0) dx_chunk<4>(gt, gs, wl, wsd, L.n, L.k, col, base, r, h, a, a1);
+            if (rem > 24) dx_chunk<16>(gt, gs, wl, wsd, col, base, r, h, a, a1);
+            else if (rem > 16) dx_chunk<12>(gt, gs, wl, wsd, col, base, r, h, a, a1);
+            else if (rem > 8) dx_chunk<8>(gt, gs, wl, wsd, col, base, r, h, a, a1);
+            else if (rem > 0) dx_chunk<4>(gt, gs, wl, wsd, col, base, r, h, a, a1);
 #pragma unroll
             for (int e = 0; e < 16; ++e) a[e] += a1[e];
             if (col < L.k) {
+              if (li == 0) {
+                if (gx) {
+                  float* gp = gx + (row0 + 4 * h) * ldgx + col;
+                  if (full) {
 #pragma unroll
-              for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (li == 0) {
-                  if (gx && row0 + row < m) ctr_stg(gx + (row0 + row) * ldgx + col, a[e]);
-                } else {
-                  xt[row * xs + col] = a[e];
+                    for (int e = 0; e < 16; ++e) ctr_stg(gp + ((e & 3) + 8 * (e >> 2)) * ldgx, a[e]);
+                  } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                      const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                      if (row0 + row < m) ctr_stg(gp + ((e & 3) + 8 * (e >> 2)) * ldgx, a[e]);
+                    }
+                  }
                 }
+              } else {
+                // X_l = Y_{l-1} sits where dX_l goes: fold act'_{l-1}(Y_{l-1}) in, so the
+                // tile leaves as gZ_{l-1} and layer l-1 needs no pass over Y from HBM.
+                // All reads first: the compiler cannot move an LDS read over an LDS write.
+                float* q = xt + 4 * h * xs + col;
+                if (act_prev != CTR_ACT_NONE) {
+                  float yv[16];
+#pragma unroll
+                  for (int e = 0; e < 16; ++e) yv[e] = q[((e & 3) + 8 * (e >> 2)) * xs];
+#pragma unroll
+                  for (int e = 0; e < 16; ++e) a[e] *= ctr_act_grad(yv[e], act_prev);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) q[((e & 3) + 8 * (e >> 2)) * xs] = a[e];
               }
             }
           }
@@ -535,40 +702,86 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
     } else {
       for (int lq = 0; lq < nlayers; ++lq) layer(lq);
     }
+    CTR_STAMP();
   }
+  CTR_STAMP();
 
-  // workgroup partial of dW / db: the 4 waves add theirs in LDS, then one slab in the workspace
+  // workgroup partial of dW / db -> one slab in the workspace.  No LDS atomics: ds_add_f32
+  // from 4 waves ran at ~200 cycles per wave-instruction here (100K cycles for the 128x64
+  // layer).  Instead every wave stores its tiles into a copy of its own (weights and
+  // activation tiles are dead, so up to 4 copies of a layer fit), in phases when fewer
+  // copies fit, and the copies are summed in a fixed order on the way to the workspace.
   const int lane = lane0, r = lane0 & 31, h = lane0 >> 5;
   __syncthreads();
-  float* s_red = lds + d.wfloats;  // reuse the activation tiles: nothing reads them any more
-  const float* s_dbv = lds + d.wfloats + kWaves * 32 * (sa + sb);  // the waves' bias partials, kept beyond the tiles
+  const int avail = wfloats + kWaves * 32 * (sa + sb);
+  float* s_red = lds;
+  const float* s_dbv = lds + avail;  // the waves' bias partials, kept beyond the tiles
   // layout of a slab: for each layer  n*k weights then n biases, in layer order
   int off = 0;
-  for (int li = 0; li < d.nlayers; ++li) {
-    const LayerDesc L = d.l[li];  // by value: registers, not an LDS reload after every LDS store
+  auto flush = [&](auto liv) __attribute__((always_inline)) {
+    const int li = (int)liv;
+    LayerDesc L = d.l[li];  // by value: registers, not an LDS reload after every LDS store
+    pin_shape<S, true>(L, li);
     const int nkt = (L.k + 31) / 32, nrt = (L.n + 31) / 32;
     const int cnt = L.n * L.k + L.n;
-    for (int i = threadIdx.x; i < cnt; i += blockDim.x) s_red[i] = 0.0f;
-    __syncthreads();
+    const int copies = 4 * cnt <= avail ? 4 : (2 * cnt <= avail ? 2 : 1);
+    float* mine = s_red + (wave & (copies - 1)) * cnt;
+    const int dboff = wave * nsum + (S::kFixed ? Y::db_off(S::kFixed ? li : 0) : d.db_off[li]);
+    for (int p = 0; p < kWaves / copies; ++p) {
+      if (wave / copies == p) {
+        // two code paths, not a select per element: the first phase is plain stores
+        // straight from the accumulator registers
 #pragma unroll
-    for (int s2 = 0; s2 < MAXT; ++s2) {
-      const int rel = s2 - L.acc_off;
-      if (rel >= 0 && rel < nrt * nkt) {
-        const int it = rel / nkt, jt = rel - it * nkt;
-        const int kcol = 32 * jt + r;
+        for (int s2 = 0; s2 < MAXT; ++s2) {
+          const int rel = s2 - L.acc_off;
+          if (rel >= 0 && rel < nrt * nkt) {
+            const int it = rel / nkt, jt = rel - it * nkt;
+            const int kcol = 32 * jt + r;
+            float* q = mine + (32 * it + 4 * h) * L.k + kcol;
+            if (kcol < L.k) {
+              if (p == 0) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int nrow = 32 * it + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (nrow < L.n && kcol < L.k) atomicAdd(s_red + nrow * L.k + kcol, dw[s2][e]);
+                for (int e = 0; e < 16; ++e) {
+                  const int rr = (e & 3) + 8 * (e >> 2);
+                  if (32 * it + 4 * h + rr < L.n) q[rr * L.k] = dw[s2][e];
+                }
+              } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                  const int rr = (e & 3) + 8 * (e >> 2);
+                  if (32 * it + 4 * h + rr < L.n) q[rr * L.k] += dw[s2][e];
+                }
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // one slot at a time: no pile-up of accumulator copies
+          }
+        }
+        for (int j = lane; j < L.n; j += 64) {
+          float* q = mine + L.n * L.k + j;
+          *q = p == 0 ? s_dbv[dboff + j] : *q + s_dbv[dboff + j];
         }
       }
+      __syncthreads();
     }
-    for (int j = lane; j < L.n; j += 64) atomicAdd(s_red + L.n * L.k + j, s_dbv[wave * d.nsum + d.db_off[li] + j]);
-    __syncthreads();
-    for (int i = threadIdx.x; i < cnt; i += blockDim.x) ws[(int64_t)blockIdx.x * slab + off + i] = s_red[i];
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+      float v = s_red[i];
+      for (int c = 1; c < copies; ++c) v += s_red[c * cnt + i];
+      ws[(int64_t)blockIdx.x * slab + off + i] = v;
+    }
     __syncthreads();
     off += cnt;
+  };
+  if constexpr (S::kFixed) {
+    static_layers(flush, std::make_integer_sequence<int, S::kLayers>{});
+  } else {
+    for (int li = 0; li < nlayers; ++li) flush(li);
   }
+  CTR_STAMP();
+#ifdef CTR_MLP_TIMING
+  if (threadIdx.x == 0)
+    for (int i = 0; i < 16; ++i)
+      ws[(int64_t)gridDim.x * slab + blockIdx.x * 16 + i] = i < nstamp ? (float)(stamps[i] - stamps[0]) : -1.0f;
+#endif
 }
 
 // ------------------------------------------------------------------ host
@@ -600,7 +813,7 @@ int build(const ctr_mlp_layer_t* layers, int nlayers, bool backward, Built* out)
     L.div_k4 = ctr_fastdiv((uint32_t)(s.k / 4));
     L.w_off = woff;
     L.acc_off = tiles;
-    woff += s.n * (s.k + 4);
+    woff += (s.n + 7) / 8 * 8 * (s.k + 4);
     L.b_off = woff;
     woff += (s.n + 3) / 4 * 4;
     tiles += ((s.n + 31) / 32) * ((s.k + 31) / 32);
@@ -641,7 +854,7 @@ int build(const ctr_mlp_layer_t* layers, int nlayers, bool backward, Built* out)
     const int64_t tiles_floats = (int64_t)kWaves * 32 * (d.sa + d.sb);
     // the flush stages one layer's n*k + n sums over the tile region, which must hold it
     CTR_REQUIRE(biggest <= tiles_floats, CTR_ELIMIT);
-    out->lds_bytes = sizeof(float) * (d.wfloats + tiles_floats + (int64_t)kWaves * nsum);
+    out->lds_bytes = sizeof(float) * (d.wfloats + tiles_floats + (int64_t)kWaves * nsum + kSlack);
   } else {
     for (int i = 0; i < nlayers; ++i) {
       int& win = (i & 1) ? wb : wa;   // layer i reads tile A (even i) / B (odd i) ...
@@ -651,19 +864,23 @@ int build(const ctr_mlp_layer_t* layers, int nlayers, bool backward, Built* out)
     }
     d.sa = wa + 4;
     d.sb = wb + 4;
-    out->lds_bytes = sizeof(float) * (d.wfloats + (int64_t)kWaves * 32 * (d.sa + d.sb));
+    out->lds_bytes = sizeof(float) * (d.wfloats + (int64_t)kWaves * 32 * (d.sa + d.sb) + kSlack);
   }
   out->slab = slab;
   CTR_REQUIRE(out->lds_bytes + sizeof(StackDesc) <= 160 * 1024, CTR_ELIMIT);
   return CTR_OK;
 }
 
-template <class S>
-bool matches(const ctr_mlp_layer_t* layers, int nlayers) {
+template <class S, bool BWD>
+bool matches(const ctr_mlp_layer_t* layers, int nlayers, const StackDesc& d) {
   if (!S::kFixed || nlayers != S::kLayers) return false;
-  for (int i = 0; i < nlayers; ++i)
+  using Y = Layout<S, BWD>;
+  for (int i = 0; i < nlayers; ++i) {
     if (layers[i].n != S::N[i] || layers[i].k != S::K[i] || layers[i].act != S::ACT[i]) return false;
-  return true;
+    if (d.l[i].w_off != Y::w_off(i) || d.l[i].b_off != Y::b_off(i) || d.l[i].acc_off != Y::acc_off(i)) return false;
+    if (BWD && d.db_off[i] != Y::db_off(i)) return false;
+  }
+  return d.sa == Y::sa() && d.sb == Y::sb() && d.wfloats == Y::wfloats() && (!BWD || d.nsum == Y::nsum());
 }
 
 template <class K>
@@ -689,7 +906,7 @@ extern "C" int ctr_mlp_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp
   const int64_t tiles = ctr_ceil_div(m, 32);
   int64_t grid = ctr_ceil_div(tiles, kWaves);
   if (grid > 256) grid = 256;  // persistent: one workgroup per CU, weights staged once
-  if (matches<NcfShape>(layers, nlayers)) {
+  if (matches<NcfShape, false>(layers, nlayers, b.d)) {
     rc = allow_lds(mlp_fwd_kernel<NcfShape>, b.lds_bytes);
     if (rc != CTR_OK) return rc;
     hipLaunchKernelGGL(mlp_fwd_kernel<NcfShape>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, (hipStream_t)stream,
@@ -728,7 +945,7 @@ extern "C" int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp
     hipLaunchKernelGGL((mlp_bwd_kernel<S, T>), dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, st, b.d, x, ldx, \
                        m, gy, ldgy, gx, ldgx, workspace, b.slab);                                                  \
   } while (0)
-  if (matches<NcfShape>(layers, nlayers)) CTR_LAUNCH_BWD(NcfShape, 14);
+  if (matches<NcfShape, true>(layers, nlayers, b.d)) CTR_LAUNCH_BWD(NcfShape, 14);
   else if (maxt == 8) CTR_LAUNCH_BWD(DynShape, 8);
   else if (maxt == 12) CTR_LAUNCH_BWD(DynShape, 12);
   else if (maxt == 14) CTR_LAUNCH_BWD(DynShape, 14);
