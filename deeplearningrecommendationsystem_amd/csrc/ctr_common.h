@@ -112,6 +112,10 @@ int ctr_reduce_segments(const float* ws, int parts, int64_t stride, const CtrSeg
 
 // internal (not part of the C ABI): single-output-unit linear layer, linear_n1.hip
 bool ctr_n1_supported(int k);
+// embed_sorted.hip: sorted segmented-reduce backward for small tables (see there)
+int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch,
+                         const float* gout, int64_t ldo, float* workspace, int64_t workspace_floats,
+                         int64_t* used_floats, unsigned char* handled, hipStream_t st);
 int ctr_n1_fwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* res, int64_t ldr, float* y,
                int64_t ldy, int64_t m, int k, int act, hipStream_t st);
 int ctr_n1_bwd(const float* x, int64_t ldx, const float* w, const float* y, int64_t ldy, const float* gy, int64_t ldgy,

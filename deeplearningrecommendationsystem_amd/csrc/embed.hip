@@ -406,7 +406,28 @@ extern "C" int ctr_embed_bwd(const ctr_field_t* fields, int nfields, const float
   if (batch == 0) return CTR_OK;
   CTR_REQUIRE(ldo > 0, CTR_EINVAL);
   Plan plan;
-  int rc = make_plan(fields, nfields, x, ldx, gout, ldo, true, &plan);
+  int rc = make_plan(fields, nfields, x, ldx, gout, ldo, true, &plan);  // validates every descriptor
+  if (rc != CTR_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  // small tables under a large batch: bucket the samples by row and reduce runs in
+  // registers (embed_sorted.hip); what it takes is dropped from the scatter launch below
+  unsigned char handled[CTR_MAX_FIELDS];
+  int64_t sort_floats = 0;
+  rc = ctr_embed_bwd_sorted(fields, nfields, x, ldx, batch, gout, ldo, workspace, workspace_floats, &sort_floats,
+                            handled, st);
+  if (rc != CTR_OK) return rc;
+  ctr_field_t rest[CTR_MAX_FIELDS];
+  int nrest = 0;
+  for (int i = 0; i < nfields; ++i) {
+    const ctr_field_t& f = fields[i];
+    const bool wants = f.kind != CTR_FIELD_DENSE && (f.grad || (f.kind == CTR_FIELD_PROD_I64 && f.grad2));
+    if (!handled[i] && wants) rest[nrest++] = f;
+  }
+  if (nrest == 0) return CTR_OK;
+  fields = rest;
+  nfields = nrest;
+  workspace_floats -= sort_floats;
+  rc = make_plan(fields, nfields, x, ldx, gout, ldo, true, &plan);
   if (rc != CTR_OK) return rc;
   CTR_REQUIRE(batch * plan.units < (1ll << 32), CTR_ELIMIT);
   const CtrFastDiv div = ctr_fastdiv((uint32_t)plan.units);
@@ -423,7 +444,6 @@ extern "C" int ctr_embed_bwd(const ctr_field_t* fields, int nfields, const float
   }
   CTR_REQUIRE(cap >= 1, CTR_ELIMIT);
   if (grid > cap) grid = cap;
-  hipStream_t st = (hipStream_t)stream;
   const size_t dyn = (size_t)plan.bag_floats * sizeof(float);
   float* ws = slabs ? workspace : nullptr;
   if (plan.vec == 4)

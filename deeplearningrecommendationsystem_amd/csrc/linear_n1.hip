@@ -60,19 +60,76 @@ struct N1BwdArgs {
   float* ws;  // per-workgroup partials [gridDim.x][k+1] (weights then bias), or NULL -> atomics
 };
 
-template <int VEC>
+// U > 1: the row needs a single chunk per lane (k <= lpr * VEC) and U rows are in flight per
+// lane -- a load-use loop over one row at a time leaves this kernel latency-bound at ~40 % of
+// the HBM rate.
+template <int VEC, int U>
 __global__ void __launch_bounds__(kBlock) n1_bwd_kernel(const N1BwdArgs a) {
   __shared__ float s_red[kBlock * VEC];
   const int sub = threadIdx.x % a.lpr;
   const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / a.lpr;
   const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / a.lpr;
-  float wacc[kMaxChunks][VEC];
+  constexpr int kChunks = U > 1 ? 1 : kMaxChunks;
+  float wacc[kChunks][VEC];
 #pragma unroll
-  for (int q = 0; q < kMaxChunks; ++q)
+  for (int q = 0; q < kChunks; ++q)
 #pragma unroll
     for (int v = 0; v < VEC; ++v) wacc[q][v] = 0.0f;
   float bacc = 0.0f;
   const bool need_w = a.gw != nullptr;
+  if constexpr (U > 1) {
+    const int c = sub * VEC;
+    const bool live = c < a.k;
+    float wv[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) wv[v] = (live && a.gx) ? a.w[c + v] : 0.0f;
+    for (int64_t r0 = gid; r0 < a.m; r0 += groups * U) {
+      float gz[U], xv[U][VEC], pv[U][VEC];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t r = r0 + u * groups;
+        const bool ok = r < a.m;
+        const int64_t rc = ok ? r : a.m - 1;
+        gz[u] = a.gy[rc * a.ldgy];
+        if (a.act != CTR_ACT_NONE) gz[u] *= ctr_act_grad(a.y[rc * a.ldy], a.act);
+        if (!ok) gz[u] = 0.0f;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) xv[u][v] = pv[u][v] = 0.0f;
+        if (live && need_w) {
+          if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(a.x + rc * a.ldx + c);
+            xv[u][0] = t.x; xv[u][1] = t.y; xv[u][2] = t.z; xv[u][VEC - 1] = t.w;
+          } else {
+            xv[u][0] = a.x[rc * a.ldx + c];
+          }
+        }
+        if (live && a.gx && a.accumulate_gx) {
+          if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(a.gx + rc * a.ldgx + c);
+            pv[u][0] = t.x; pv[u][1] = t.y; pv[u][2] = t.z; pv[u][VEC - 1] = t.w;
+          } else {
+            pv[u][0] = a.gx[rc * a.ldgx + c];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t r = r0 + u * groups;
+        if (sub == 0) bacc += gz[u];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) wacc[0][v] = fmaf(gz[u], xv[u][v], wacc[0][v]);
+        if (live && a.gx && r < a.m) {
+          if (VEC == 4) {
+            *reinterpret_cast<float4*>(a.gx + r * a.ldgx + c) =
+                make_float4(fmaf(gz[u], wv[0], pv[u][0]), fmaf(gz[u], wv[1], pv[u][1]), fmaf(gz[u], wv[2], pv[u][2]),
+                            fmaf(gz[u], wv[VEC - 1], pv[u][VEC - 1]));
+          } else {
+            a.gx[r * a.ldgx + c] = fmaf(gz[u], wv[0], pv[u][0]);
+          }
+        }
+      }
+    }
+  } else {
   for (int64_t r = gid; r < a.m; r += groups) {
     float gz = a.gy[r * a.ldgy];
     if (a.act != CTR_ACT_NONE) gz *= ctr_act_grad(a.y[r * a.ldy], a.act);
@@ -80,14 +137,14 @@ __global__ void __launch_bounds__(kBlock) n1_bwd_kernel(const N1BwdArgs a) {
     const float* xr = a.x ? a.x + r * a.ldx : nullptr;
     float* gxr = a.gx ? a.gx + r * a.ldgx : nullptr;
 #pragma unroll
-    for (int q = 0; q < kMaxChunks; ++q) {
+    for (int q = 0; q < kChunks; ++q) {
       const int c = (sub + q * a.lpr) * VEC;
       if (c < a.k) {
         if (VEC == 4) {
           if (need_w) {
             const float4 xv = *reinterpret_cast<const float4*>(xr + c);
             wacc[q][0] = fmaf(gz, xv.x, wacc[q][0]); wacc[q][1] = fmaf(gz, xv.y, wacc[q][1]);
-            wacc[q][2] = fmaf(gz, xv.z, wacc[q][2]); wacc[q][3] = fmaf(gz, xv.w, wacc[q][3]);
+            wacc[q][2] = fmaf(gz, xv.z, wacc[q][2]); wacc[q][VEC - 1] = fmaf(gz, xv.w, wacc[q][VEC - 1]);
           }
           if (gxr) {
             const float4 wv = *reinterpret_cast<const float4*>(a.w + c);
@@ -105,11 +162,12 @@ __global__ void __launch_bounds__(kBlock) n1_bwd_kernel(const N1BwdArgs a) {
       }
     }
   }
+  }
   // reduce the per-group partials of the workgroup, chunk by chunk
   const int ngroups = kBlock / a.lpr;
   if (need_w) {
 #pragma unroll
-    for (int q = 0; q < kMaxChunks; ++q) {
+    for (int q = 0; q < kChunks; ++q) {
       if (q * a.lpr * VEC >= a.k) break;
       __syncthreads();
 #pragma unroll
@@ -185,10 +243,15 @@ int ctr_n1_bwd(const float* x, int64_t ldx, const float* w, const float* y, int6
   const bool slabs = gw && ws && ws_floats >= (int64_t)grid * (k + 1) && grid > 8;
   if (!slabs && grid > 128) grid = 128;  // same-address atomics serialise: keep the chains short
   N1BwdArgs a{x, ldx, w, y, ldy, gy, ldgy, gx, ldgx, accumulate_gx, gw, gb, m, k, act, lpr, slabs ? ws : nullptr};
-  if (vec)
-    hipLaunchKernelGGL(n1_bwd_kernel<4>, dim3(grid), dim3(kBlock), 0, st, a);
+  const bool single = (vec ? 4 : 1) * lpr >= k && x && w;  // one chunk per lane: 4 rows in flight
+  if (vec && single)
+    hipLaunchKernelGGL((n1_bwd_kernel<4, 4>), dim3(grid), dim3(kBlock), 0, st, a);
+  else if (vec)
+    hipLaunchKernelGGL((n1_bwd_kernel<4, 1>), dim3(grid), dim3(kBlock), 0, st, a);
+  else if (single)
+    hipLaunchKernelGGL((n1_bwd_kernel<1, 4>), dim3(grid), dim3(kBlock), 0, st, a);
   else
-    hipLaunchKernelGGL(n1_bwd_kernel<1>, dim3(grid), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL((n1_bwd_kernel<1, 1>), dim3(grid), dim3(kBlock), 0, st, a);
   int rc = ctr_launch_status();
   if (rc != CTR_OK || !slabs) return rc;
   CtrSegments segs;

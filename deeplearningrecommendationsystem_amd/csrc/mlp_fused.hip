@@ -503,13 +503,16 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
   const int nl = S::kFixed ? S::N[S::kFixed ? S::kLayers - 1 : 0] : d.l[last].n;
   constexpr bool kPre = S::kFixed;
   const int64_t tstride = (int64_t)gridDim.x * kWaves;
-  float4 pre[16];  // kPre: the next layer-input tile, in flight
+  float4 pre[16];   // kPre: the next layer-input tile, in flight
+  float4 gpre[16];  // kPre: the next tile's gY
+  const bool gvec = kPre && nl % 4 == 0 && ldgy % 4 == 0 && (reinterpret_cast<uintptr_t>(gy) & 15) == 0;
   const float* xlast = last > 0 ? d.l[last > 0 ? last - 1 : 0].y : x;
   const int64_t ldxlast = last > 0 ? d.l[last > 0 ? last - 1 : 0].ldy : ldx;
   if constexpr (kPre) {
     const int64_t t0 = (int64_t)blockIdx.x * kWaves + wave;
     pre_issue<true>(pre, xlast, ldxlast, t0 * 32, m, S::K[S::kFixed ? S::kLayers - 1 : 0], d.l[last].div_k4, lane0,
                     t0 < tiles);
+    if (gvec) pre_issue<true>(gpre, gy, ldgy, t0 * 32, m, nl, div_last, lane0, t0 < tiles);
   }
   for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += tstride) {
     const int64_t row0 = tile * 32;
@@ -520,8 +523,10 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
     int lane = lane0;
     if constexpr (S::kFixed) asm volatile("" : "+v"(lane));
     const int r = lane & 31, h = lane >> 5;
-    // gradient of the last layer's output -> P
-    tile_load1<8, S::kFixed>(tp, sa, gy, ldgy, row0, m, nl, div_last, lane);
+    // gradient of the last layer's output -> P (requested during the previous tile's
+    // layer 0 when it can be fetched as dwordx4)
+    if (kPre && gvec) pre_commit<true>(gpre, tp, sa, nl, div_last, lane);
+    else tile_load1<8, S::kFixed>(tp, sa, gy, ldgy, row0, m, nl, div_last, lane);
     __builtin_amdgcn_wave_barrier();
     {
       // gZ = gY * act'(Y) of the last layer, in place (rows past m stay zero)
@@ -573,6 +578,7 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
             const int64_t nt = tile + tstride;
             pre_issue<true>(pre, xlast, ldxlast, nt * 32, m, S::K[S::kFixed ? S::kLayers - 1 : 0], d.l[last].div_k4, lane,
                             nt < tiles);
+            if (gvec) pre_issue<true>(gpre, gy, ldgy, nt * 32, m, nl, div_last, lane, nt < tiles);
           }
         } else {
           tile_load4<4, S::kFixed>(xt, xs, src, ld_in, row0, m, L.k, L.div_k4, lane);

@@ -184,7 +184,7 @@ def embed_bwd(specs: Sequence[FieldSpec], x: Optional[torch.Tensor], batch: int,
     if x is not None:
         x = _mat(x, "x")
     arr = _field_array(specs, grads)
-    ws = _scratch(gout.device) if any(s.kind == FIELD_BAG for s in specs) else None
+    ws = _scratch(gout.device)  # bag partials + the sort buffers of the small-table path
     rc = _timed("embed_bwd", lambda: (_embed_bytes(specs, batch, True), 0),
                 _lib.load().ctr_embed_bwd, arr, len(specs), _lib.ptr(x), _ld(x) if x is not None else 0, batch,
                 gout.data_ptr(), _ld(gout), _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream_ptr())

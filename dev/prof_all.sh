@@ -7,7 +7,7 @@ for w in "$@"; do
   python3 - "$w" <<'PY'
 import csv,glob,sys
 w=sys.argv[1]
-f=glob.glob(f'/root/repo/gpurun_out/prof_{w}/*/*kernel_stats.csv')[0]
+import os; f=max(glob.glob(f'/root/repo/gpurun_out/prof_{w}/*/*kernel_stats.csv'), key=os.path.getmtime)
 rows=list(csv.DictReader(open(f)))
 tot=sum(float(r['TotalDurationNs']) for r in rows)
 print(f"=== {w}: total kernel time per step {tot/23/1e3:.1f} us (23 steps incl warmup+profile pass)")

@@ -106,6 +106,36 @@ def test_embed_id_i64_prod_dense_and_strided_output(ops):
     torch.testing.assert_close(grads[id(d2)].cpu(), l2.grad, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("batch,e", [(20000, 32), (65536, 64), (4099, 4)])
+def test_embed_backward_small_tables_sorted_path(ops, batch, e):
+    # tables much smaller than the batch take the counting-sort + run-reduce backward
+    # (embed_sorted.hip); same contract as the atomic scatter: dense grads, fp32 sums
+    L = _lib()
+    g = torch.Generator().manual_seed(batch + e)
+    v1, v2 = 300, 500
+    t1, t2 = torch.randn(v1, e, generator=g), torch.randn(v2, e, generator=g)
+    p1, p2 = torch.randn(v1, e, generator=g), torch.randn(v2, e, generator=g)
+    # skewed ids (a few very long runs) incl. both ends of the range
+    i1 = (torch.rand(batch, generator=g) ** 3 * v1).long().clamp_(0, v1 - 1)
+    i2 = torch.randint(0, v2, (batch,), generator=g)
+    i1[0], i1[1], i2[0], i2[1] = 0, v1 - 1, 0, v2 - 1
+    dev = {k: v.to(DEV) for k, v in dict(t1=t1, t2=t2, p1=p1, p2=p2, i1=i1, i2=i2).items()}
+    specs = [
+        ops.FieldSpec(L.FIELD_ID_I64, e, 0, table=dev["t1"], idx=dev["i1"]),
+        ops.FieldSpec(L.FIELD_ID_I64, e, e, table=dev["t2"], idx=dev["i2"]),
+        ops.FieldSpec(L.FIELD_PROD_I64, e, 2 * e, table=dev["p1"], idx=dev["i1"], table2=dev["p2"], idx2=dev["i2"]),
+    ]
+    gout = torch.randn(batch, 3 * e, generator=g)
+    leaf = {k: v.double().requires_grad_(True) for k, v in dict(t1=t1, t2=t2, p1=p1, p2=p2).items()}
+    ref = torch.cat([leaf["t1"][i1], leaf["t2"][i2], leaf["p1"][i1] * leaf["p2"][i2]], 1)
+    ref.backward(gout.double())
+    grads = {id(dev[k]): torch.zeros_like(dev[k]) for k in ("t1", "t2", "p1", "p2")}
+    ops.embed_bwd(specs, None, batch, gout.to(DEV), grads)
+    for k in ("t1", "t2", "p1", "p2"):
+        torch.testing.assert_close(grads[id(dev[k])].cpu(), leaf[k].grad.float(), rtol=1e-5,
+                                   atol=1e-6 + 3e-6 * batch ** 0.5, msg=lambda m, k=k: f"grad of {k}: {m}")
+
+
 def test_embed_sequence_gather_is_bit_exact(ops):
     # K3: (B,L) history gathered column by column through idx_stride
     L = _lib()
