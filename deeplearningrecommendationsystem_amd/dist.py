@@ -27,32 +27,83 @@ import torch.distributed as dist
 
 
 class GradBucket:
-    """flat fp32 bucket holding the gradients of ``params`` (fixed order)"""
+    """averages the gradients of ``params`` over the ranks with as few collectives as possible.
+
+    The zoo's backward passes carve every dense ``.grad`` out of ONE zero-filled flat buffer
+    (``ops.zero_grads``), so after ``backward()`` all gradients usually share a single
+    storage: that storage is all-reduced in place -- one collective, no packing copies.
+    Gradients that live elsewhere (plain torch modules, CPU tests) take the classic
+    pack -> all-reduce -> unpack path through a flat bucket (fixed order)."""
+
+    MAX_STORAGES = 4  # more distinct storages than this: packing is cheaper than the collectives
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
-        total = sum(p.numel() for p in self.params)
-        ref = self.params[0]
-        self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
-        self.views = []
-        off = 0
+        self._flat = None       # packing bucket, allocated on first use
+        self._views = None
+        self._shared = {}       # storage data_ptr -> flat fp32 view of the whole storage
+
+    def _pack_bucket(self):
+        if self._flat is None:
+            total = sum(p.numel() for p in self.params)
+            ref = self.params[0]
+            self._flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+            self._views, off = [], 0
+            for p in self.params:
+                self._views.append(self._flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        return self._flat, self._views
+
+    def _shared_storages(self):
+        """flat views over the storages holding every gradient, or None when packing is better"""
+        seen = {}
         for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+            g = p.grad
+            if g is None or g.dtype != torch.float32 or not g.is_contiguous():
+                return None
+            st = g.untyped_storage()
+            key = st.data_ptr()
+            if key not in seen:
+                if len(seen) == self.MAX_STORAGES or st.nbytes() % 4:
+                    return None
+                flat = self._shared.get(key)
+                if flat is None or flat.numel() != st.nbytes() // 4:
+                    flat = torch.empty(0, dtype=torch.float32, device=g.device).set_(st, 0, (st.nbytes() // 4,))
+                    self._shared[key] = flat
+                seen[key] = flat
+        return list(seen.values())
+
+    @staticmethod
+    def _mean(flat: torch.Tensor, group) -> None:
+        world = dist.get_world_size(group)
+        if dist.get_backend(group) == "nccl":
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)  # RCCL averages in the collective
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            flat.mul_(1.0 / world)
 
     def all_reduce_mean(self, group=None) -> None:
         """average gradients over the ranks (no-op for a single process)"""
         if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
             return
+        shared = self._shared_storages()
+        if shared is not None:
+            for flat in shared:
+                self._mean(flat, group)
+            return
+        flat, views = self._pack_bucket()
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        torch._foreach_copy_(self.views, grads)
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        self.flat.mul_(1.0 / dist.get_world_size(group))
-        for p, v in zip(self.params, self.views):
+        torch._foreach_copy_(views, grads)
+        self._mean(flat, group)
+        for p, v in zip(self.params, views):
             if p.grad is None:
                 p.grad = v.clone()
             else:
                 p.grad.copy_(v)
+
+    @property
+    def flat(self) -> torch.Tensor:
+        return self._pack_bucket()[0]
 
 
 # ---------------------------------------------------------------------------

@@ -84,6 +84,25 @@ def _bucket_worker(rank, world, port, out):
         GradBucket(lin.parameters()).all_reduce_mean()
         for p, g in zip(lin.parameters(), local):
             torch.testing.assert_close(p.grad, g * (1 + 2) / 2 / (rank + 1))
+        # gradients carved from one flat buffer (what ops.zero_grads hands to autograd):
+        # the shared storage is reduced in place, one collective, and .grad stays a view of it
+        ps = [torch.nn.Parameter(torch.zeros(n)) for n in (4, 8, 3)]
+        flat = torch.arange(16, dtype=torch.float32) * (rank + 1)
+        ps[0].grad, ps[1].grad, ps[2].grad = flat[0:4], flat[4:12], flat[12:15]
+        b = GradBucket(ps)
+        assert len(b._shared_storages()) == 1
+        b.all_reduce_mean()
+        torch.testing.assert_close(flat, torch.arange(16, dtype=torch.float32) * 1.5)
+        assert ps[1].grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
+        # many separately allocated gradients: packed into one bucket instead
+        many = [torch.nn.Parameter(torch.zeros(2)) for _ in range(GradBucket.MAX_STORAGES + 2)]
+        for i, q in enumerate(many):
+            q.grad = torch.full((2,), float((i + 1) * (rank + 1)))
+        b = GradBucket(many)
+        assert b._shared_storages() is None
+        b.all_reduce_mean()
+        for i, q in enumerate(many):
+            torch.testing.assert_close(q.grad, torch.full((2,), (i + 1) * 1.5))
         out.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         out.put((rank, repr(e)))
