@@ -45,6 +45,9 @@ WORKLOADS = {
     "deepcrossing": "deepcrossing emb=32 hidden=[256,128,64,32] ml-100k vocab batch=65536/gpu",
     "din": "din items=1e7 emb=64 L=100 batch=32768/gpu (BASELINE configs[4], single GPU)",
     "dien": "dien items=1e7 emb=16 L=100 batch=32768/gpu (BASELINE configs[4], single GPU)",
+    # the embedding stage alone at the roofline shape of SURVEY.md 8(d) cfg3b (metric ii: gather GB/s)
+    "gather26": "embedding stage 26 fields x 1e6 rows x emb=16 batch=65536/gpu, uniform ids (gather fwd + dense-grad scatter bwd)",
+    "gather26zipf": "embedding stage 26 fields x 1e6 rows x emb=16 batch=65536/gpu, Zipf(1.05) ids",
 }
 
 
@@ -61,6 +64,14 @@ def make_inputs(name: str, rank: int, batch: int):
     if name in ("din", "dien"):
         hist, target = synth.hist_batch(batch, 100, 10_000_000, gen)
         return [hist, target], synth.labels(batch, True, gen)
+    if name in ("gather26", "gather26zipf"):
+        if name == "gather26":
+            idx = torch.randint(0, 1_000_000, (batch, 26), generator=gen)
+        else:  # rank r of a Zipf(1.05) law over the 1e6 rows, by inverse-CDF on a log grid
+            u = torch.rand(batch, 26, generator=gen, dtype=torch.float64)
+            idx = ((1_000_000.0 ** u - 1.0)).long().clamp_(0, 999_999)  # alpha ~ 1: P(rank<=r) ~ log r / log V
+        # the "target" is the gradient fed back into the stage (fixed, N(0,1))
+        return [idx], torch.randn(batch, 26 * 16, generator=gen)
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -83,6 +94,8 @@ def make_model(name: str):
         return zoo.DIN(10_000_000, 64)
     if name == "dien":
         return zoo.DIEN(10_000_000, 16)
+    if name in ("gather26", "gather26zipf"):
+        return zoo.EmbeddingStage(26, 1_000_000, 16)
     raise SystemExit(f"unknown workload {name}")
 
 
@@ -96,6 +109,19 @@ def build_workload(name: str, device, rank: int):
     m = make_model(name)
     inputs, y = make_inputs(name, rank, batch_of(name))
     return m.to(device), [t.to(device) for t in inputs], y.to(device), WORKLOADS[name]
+
+
+class _FeedGradient(torch.autograd.Function):
+    """"loss" of the gather workloads: a zero scalar whose backward hands `grad` to the stage output"""
+
+    @staticmethod
+    def forward(ctx, out, grad):
+        ctx.save_for_backward(grad)
+        return out.new_zeros(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.saved_tensors[0], None
 
 
 def cpu_baseline(name: str, model, budget_s: float = 15.0):
@@ -196,6 +222,8 @@ def main():
 
     model, inputs, y, desc = build_workload(args.workload, device, rank)
     loss_fn = BCELoss()  # drop-in for torch.nn.BCELoss(), parity-tested against it
+    if args.workload.startswith("gather26"):
+        loss_fn = _FeedGradient.apply  # no head on the bare embedding stage: backward starts from a fixed gradient
     bucket = GradBucket(model.parameters()) if world > 1 else None
     model.train()
 
@@ -272,7 +300,9 @@ def main():
         dominant = max(kernels, key=lambda k: kernels[k]["total_us"])
         kernel_us = sum(v["total_us"] for v in kernels.values()) / args.steps
         out = {
-            "metric": "CTR samples/sec fwd+bwd at batch 65536" if batch_of(args.workload) == BATCH else
+            "metric": "embedding-stage samples/sec (26-field gather fwd + scatter bwd) at batch 65536"
+                      if args.workload.startswith("gather26") else
+                      "CTR samples/sec fwd+bwd at batch 65536" if batch_of(args.workload) == BATCH else
                       f"CTR samples/sec fwd+bwd at batch {batch_of(args.workload)}",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -9,5 +9,6 @@ from .ffm import FFM
 from .deepcrossing import DeepCrossing
 from .din import DIN
 from .dien import DIEN
+from .embedding_stage import EmbeddingStage
 
-__all__ = ["MatrixFactorization", "NeuralCF", "DeepFM", "PNN", "FFM", "DeepCrossing", "DIN", "DIEN"]
+__all__ = ["MatrixFactorization", "NeuralCF", "DeepFM", "PNN", "FFM", "DeepCrossing", "DIN", "DIEN", "EmbeddingStage"]

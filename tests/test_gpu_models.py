@@ -173,6 +173,26 @@ def test_dien_config5_shape_against_oracle():
     _vs_oracle("dien", DIEN(100_000, 16), inputs, y)
 
 
+@pytest.mark.parametrize("fields,vocab,dim,batch", [(26, 5000, 16, 4096), (3, 50, 8, 1000), (5, 100000, 64, 777)])
+def test_embedding_stage_gathers_bit_exact_and_scatters_dense_grads(fields, vocab, dim, batch):
+    # generalised F-field stage (SURVEY 8d cfg3b shape at test size): forward == torch.cat of
+    # nn.Embedding lookups bit for bit, backward == embedding_dense_backward per table
+    from deeplearningrecommendationsystem_amd.model import EmbeddingStage
+    torch.manual_seed(fields)
+    stage = EmbeddingStage(fields, vocab, dim).to(DEV)
+    g = torch.Generator().manual_seed(batch)
+    idx = torch.randint(0, vocab, (batch, fields), generator=g)
+    gout = torch.randn(batch, fields * dim, generator=g)
+    out = stage(idx.to(DEV))
+    out.backward(gout.to(DEV))
+    tabs = [t.detach().cpu() for t in stage.tables]
+    assert torch.equal(out.detach().cpu(), torch.cat([tabs[f][idx[:, f]] for f in range(fields)], 1))
+    for f in range(fields):
+        ref = torch.zeros(vocab, dim, dtype=torch.float64)
+        ref.index_add_(0, idx[:, f], gout[:, f * dim:(f + 1) * dim].double())
+        torch.testing.assert_close(stage.tables[f].grad.cpu(), ref.float(), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("name", ["neuralcf", "pnn", "din"])
 def test_gradients_of_a_model_share_one_storage_for_the_data_parallel_all_reduce(name):
     # dist.GradBucket reduces the storage behind the gradients in place when there are few
