@@ -147,21 +147,25 @@ embed_fwd_kernel(const FieldPack P, int nfields, const float* __restrict__ x, in
 template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 embed_bwd_kernel(const FieldPack P, int nfields, const float* __restrict__ x, int64_t ldx, uint32_t batch,
-                 const float* __restrict__ gout, int64_t ldo, int bag_floats, const CtrFastDiv div,
+                 const float* __restrict__ gout, int64_t ldo, int bag_floats, int hot_floats, const CtrFastDiv div,
                  float* __restrict__ ws /* [gridDim.x][bag_floats] partials, or NULL -> atomics */) {
   using V = typename Vec<VEC>::T;
   __shared__ UnitLut s;
   __shared__ int s_bag_off[CTR_MAX_FIELDS];
-  extern __shared__ float s_bag[];  // bag_floats accumulators
+  __shared__ int s_hot_off[CTR_MAX_FIELDS];
+  extern __shared__ float s_bag[];  // bag_floats accumulators, then hot_floats for row 0 of the id fields
+  float* s_hot = s_bag + bag_floats;
   build_lut<VEC>(s, P, nfields);
   if (threadIdx.x == 0) {
-    int acc = 0;
+    int acc = 0, hot = 0;
     for (int f = 0; f < nfields; ++f) {
       s_bag_off[f] = acc;
+      s_hot_off[f] = hot;
       if (s.f[f].kind == CTR_FIELD_BAG && s.f[f].grad) acc += s.f[f].bag_size * s.f[f].width;
+      if ((s.f[f].kind == CTR_FIELD_ID_I64 || s.f[f].kind == CTR_FIELD_ID_F32) && s.f[f].grad) hot += s.f[f].width;
     }
   }
-  for (int i = threadIdx.x; i < bag_floats; i += blockDim.x) s_bag[i] = 0.0f;
+  for (int i = threadIdx.x; i < bag_floats + hot_floats; i += blockDim.x) s_bag[i] = 0.0f;
   __syncthreads();
 
   const uint32_t upr = div.d;
@@ -182,7 +186,11 @@ embed_bwd_kernel(const FieldPack P, int nfields, const float* __restrict__ x, in
         int64_t r = f.kind == CTR_FIELD_ID_I64 ? ctr_ldg(f.idx + (int64_t)b * f.idx_stride)
                                                 : (int64_t)x[(int64_t)b * ldx + f.src_col];
         if (r < 0 || r >= f.vocab) r = 0;
-        atomic_add_vec(f.grad + r * f.width + off, gv);
+        // Row 0 is the padding id of the behaviour sequences (scripts/din.py:23-31: a quarter of
+        // a history is zeros): hundreds of thousands of same-address atomics would serialise
+        // (~60 ns each).  It is summed per workgroup in LDS and flushed once.
+        if (VEC == 1 && r == 0 && hot_floats > 0) atomicAdd(s_hot + s_hot_off[fi] + off, reinterpret_cast<const float*>(&gv)[0]);
+        else atomic_add_vec(f.grad + r * f.width + off, gv);
       } break;
       case CTR_FIELD_BAG: {
         if (!f.grad) break;
@@ -211,6 +219,16 @@ embed_bwd_kernel(const FieldPack P, int nfields, const float* __restrict__ x, in
     }
   }
   __syncthreads();
+  if (hot_floats > 0) {
+    for (int fi = 0; fi < nfields; ++fi) {
+      const ctr_field_t& f = s.f[fi];
+      if ((f.kind != CTR_FIELD_ID_I64 && f.kind != CTR_FIELD_ID_F32) || !f.grad) continue;
+      for (int i = threadIdx.x; i < f.width; i += blockDim.x) {
+        const float v = s_hot[s_hot_off[fi] + i];
+        if (v != 0.0f) ctr_atomic_add_global(f.grad + i, v);
+      }
+    }
+  }
   if (ws) {
     // plain stores of this workgroup's partial; reduce.hip adds the partials up
     for (int i = threadIdx.x; i < bag_floats; i += blockDim.x) ws[(int64_t)blockIdx.x * bag_floats + i] = s_bag[i];
@@ -444,14 +462,19 @@ extern "C" int ctr_embed_bwd(const ctr_field_t* fields, int nfields, const float
   }
   CTR_REQUIRE(cap >= 1, CTR_ELIMIT);
   if (grid > cap) grid = cap;
-  const size_t dyn = (size_t)plan.bag_floats * sizeof(float);
+  int hot_floats = 0;
+  for (int i = 0; i < nfields; ++i)
+    if ((fields[i].kind == CTR_FIELD_ID_I64 || fields[i].kind == CTR_FIELD_ID_F32) && fields[i].grad)
+      hot_floats += fields[i].width;
+  if (hot_floats > 4096) hot_floats = 0;  // keep the LDS footprint small: very wide stages scatter row 0 directly
+  const size_t dyn = (size_t)(plan.bag_floats + hot_floats) * sizeof(float);
   float* ws = slabs ? workspace : nullptr;
   if (plan.vec == 4)
     hipLaunchKernelGGL(embed_bwd_kernel<4>, dim3(grid), dim3(kBlock), dyn, st, plan.pack, nfields, x, ldx,
-                       (uint32_t)batch, gout, ldo, plan.bag_floats, div, ws);
+                       (uint32_t)batch, gout, ldo, plan.bag_floats, hot_floats, div, ws);
   else
     hipLaunchKernelGGL(embed_bwd_kernel<1>, dim3(grid), dim3(kBlock), dyn, st, plan.pack, nfields, x, ldx,
-                       (uint32_t)batch, gout, ldo, plan.bag_floats, div, ws);
+                       (uint32_t)batch, gout, ldo, plan.bag_floats, hot_floats, div, ws);
   rc = ctr_launch_status();
   if (rc != CTR_OK || !slabs) return rc;
   CtrSegments segs;

@@ -38,7 +38,9 @@ class GradBucket:
     MAX_STORAGES = 4  # more distinct storages than this: packing is cheaper than the collectives
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
-        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        # row shards (ShardedEmbedding.weight) are different rows on every rank: never averaged
+        self.params: List[torch.nn.Parameter] = [p for p in params
+                                                 if p.requires_grad and not getattr(p, "ctr_row_shard", False)]
         self._flat = None       # packing bucket, allocated on first use
         self._views = None
         self._shared = {}       # storage data_ptr -> flat fp32 view of the whole storage
@@ -152,9 +154,20 @@ class HipShardBackend:
             ops.embed_bwd([spec], None, n, rows, {id(grad): grad})
 
 
+def _host_staged(t: torch.Tensor, group) -> bool:
+    """gloo has no device all-to-all: rehearsals with several ranks on one GPU go through the host"""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def _exchange(send: torch.Tensor, send_counts: List[int], recv_counts: List[int], group) -> torch.Tensor:
     """all_to_all_single with per-rank row counts; trailing dims are kept"""
-    out = torch.empty((sum(recv_counts),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+    shape = (sum(recv_counts),) + tuple(send.shape[1:])
+    if _host_staged(send, group):
+        out = torch.empty(shape, dtype=send.dtype)
+        dist.all_to_all_single(out, send.contiguous().cpu(), output_split_sizes=recv_counts,
+                               input_split_sizes=send_counts, group=group)
+        return out.to(send.device)
+    out = torch.empty(shape, dtype=send.dtype, device=send.device)
     dist.all_to_all_single(out, send.contiguous(), output_split_sizes=recv_counts, input_split_sizes=send_counts,
                            group=group)
     return out
@@ -167,8 +180,12 @@ class _ShardedLookup(torch.autograd.Function):
         flat = ids.reshape(-1).contiguous()
         counts, send_ids, perm, inv = be.bucket(flat, world)
         send_counts = [int(c) for c in counts.tolist()]                  # one host sync per lookup
-        recv_counts_t = torch.empty_like(counts)
-        dist.all_to_all_single(recv_counts_t, counts, group=group)
+        if _host_staged(counts, group):
+            recv_counts_t = torch.empty(world, dtype=counts.dtype)
+            dist.all_to_all_single(recv_counts_t, counts.cpu(), group=group)
+        else:
+            recv_counts_t = torch.empty_like(counts)
+            dist.all_to_all_single(recv_counts_t, counts, group=group)
         recv_counts = [int(c) for c in recv_counts_t.tolist()]
         recv_ids = _exchange(send_ids, send_counts, recv_counts, group)   # local rows other ranks want
         rows = be.gather_rows(weight, recv_ids)                           # this shard's rows
@@ -188,6 +205,11 @@ class _ShardedLookup(torch.autograd.Function):
         g_owner = _exchange(g_bucketed, ctx.send_counts, ctx.recv_counts, group)      # to the owners
         grad = torch.zeros_like(weight)
         be.scatter_add_rows(grad, recv_ids, g_owner)
+        if ctx.module.average:
+            # every rank's loss is a mean over ITS samples and the replicated parameters are
+            # averaged over the ranks (GradBucket): the shard sums contributions of all ranks'
+            # samples, so the same global-mean gradient needs the 1/world here
+            grad.mul_(1.0 / ctx.module.world)
         return grad, None, None
 
 
@@ -198,8 +220,10 @@ class ShardedEmbedding(torch.nn.Module):
     ``r % world``.  ``forward(ids)`` returns the same values as the full table would
     (bit-exact: rows are only copied)."""
 
-    def __init__(self, num_embeddings: int, embedding_dim: int, group=None, backend=None, device=None):
+    def __init__(self, num_embeddings: int, embedding_dim: int, group=None, backend=None, device=None,
+                 average: bool = True):
         super().__init__()
+        self.average = average
         if not dist.is_initialized():
             raise RuntimeError("ShardedEmbedding needs torch.distributed to be initialised")
         self.group = group
@@ -209,6 +233,7 @@ class ShardedEmbedding(torch.nn.Module):
         self.backend = backend if backend is not None else HipShardBackend()
         local_rows = (num_embeddings - self.rank + self.world - 1) // self.world
         self.weight = torch.nn.Parameter(torch.empty(max(local_rows, 1), embedding_dim, device=device))
+        self.weight.ctr_row_shard = True  # GradBucket leaves it alone
         torch.nn.init.normal_(self.weight, std=(2.0 / (num_embeddings + embedding_dim)) ** 0.5)  # xavier_normal_ of the full table
 
     @torch.no_grad()

@@ -7,19 +7,21 @@ from torch.nn.init import xavier_normal_
 
 from .. import ops
 from ..ops import ACT_NONE, Layer
-from .din import SequenceModel, attention_layers, fc_layers
+from .din import SequenceModel, _zero_grads, attention_layers, fc_layers
 
 
 class DIN(nn.Module):
     """parameter container of DIEN's attention unit (reference model/dien.py:8-39:
     attention MLP 3E -> 64 -> 32 -> 1, returns the un-summed weighted history)"""
 
-    def __init__(self, num_items, embed_size):
+    def __init__(self, num_items, embed_size, table=None):
         super().__init__()
-        self.item_embedding = nn.Embedding(num_items, embed_size)
+        if table is None:
+            table = nn.Embedding(num_items, embed_size)
+            xavier_normal_(table.weight.data)
+        self.item_embedding = table
         self.attention = nn.Sequential(nn.Linear(embed_size * 3, 64), nn.ReLU(), nn.Linear(64, 32), nn.ReLU(),
                                        nn.Linear(32, 1))
-        xavier_normal_(self.item_embedding.weight.data)
 
 
 class DIEN(SequenceModel):
@@ -29,9 +31,10 @@ class DIEN(SequenceModel):
     B*L rows -> sequential GRU kernel (h0 = 0) -> hidden[-1] lands in the left half
     of the fc input next to t -> fc MLP + sigmoid."""
 
-    def __init__(self, num_items, embed_size):
+    def __init__(self, num_items, embed_size, *, sharded=False, group=None):
         super().__init__()
-        self.din = DIN(num_items, embed_size)
+        self.sharded = bool(sharded)
+        self.din = DIN(num_items, embed_size, self._make_table(num_items, embed_size, sharded, group))
         self.interest_evolution = nn.GRU(embed_size, embed_size, batch_first=True)
         self.fc = nn.Sequential(nn.Linear(embed_size * 2, 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU(),
                                 nn.Linear(64, 1), nn.Sigmoid())
@@ -47,7 +50,12 @@ class DIEN(SequenceModel):
         return p
 
     def forward(self, hist, target_item):
-        return self._run_sequence(hist, target_item, self._params())
+        params = self._params()
+        if self.sharded:
+            self._need_device(hist, target_item, params[0])
+            rows, hist, target_item = self._lookup_sharded(self.din.item_embedding, hist, target_item)
+            params[0] = rows
+        return self._run_sequence(hist, target_item, params)
 
     def run_forward(self, inputs, params):
         hist, target = inputs
@@ -80,7 +88,7 @@ class DIEN(SequenceModel):
         dim = table.shape[1]
         dev = table.device
         c = att_acts[0]
-        zeros = ops.zero_grads(params)
+        zeros = _zero_grads(self, params)
         fc_grads, gfcin = ops.mlp_bwd(fc_acts, fc, gprob, None, zeros=zeros)
         dgi = torch.empty((batch * length, 3 * dim), dtype=torch.float32, device=dev)
         dgh = torch.empty((batch * (length + 1), 3 * dim), dtype=torch.float32, device=dev)

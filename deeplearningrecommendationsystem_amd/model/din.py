@@ -20,8 +20,40 @@ def fc_layers(p):
     return [Layer(p[0], p[1], ACT_RELU), Layer(p[2], p[3], ACT_RELU), Layer(p[4], p[5], ACT_SIGMOID)]
 
 
+def _zero_grads(model, params):
+    """one flat zero buffer for the parameters' gradients; the exchanged rows of a sharded
+    table are an activation, not a replicated parameter: their gradient gets its own buffer
+    so that the data-parallel all-reduce of the flat one does not carry it"""
+    if not getattr(model, "sharded", False):
+        return ops.zero_grads(params)
+    zeros = ops.zero_grads(params[1:])
+    zeros[id(params[0])] = torch.zeros_like(params[0])
+    return zeros
+
+
 class SequenceModel(CtrModule):
     """shared plumbing of the (hist, target) models"""
+
+    def _make_table(self, num_items, embed_size, sharded, group):
+        """``nn.Embedding`` like the reference, or -- keyword-only extension for the 1e7-row
+        multi-GPU configs -- its row-sharded counterpart (dist.ShardedEmbedding)"""
+        if not sharded:
+            emb = nn.Embedding(num_items, embed_size)
+            xavier_normal_(emb.weight.data)
+            return emb
+        from ..dist import ShardedEmbedding
+        return ShardedEmbedding(num_items, embed_size, group=group)
+
+    def _lookup_sharded(self, table_module, hist, target):
+        """rows of every (hist, target) id through the all-to-all exchange, then the model runs
+        on them as if they were a (B*L+B)-row table indexed 0..B*L+B-1: the kernels are unchanged,
+        their table gradient becomes the gradient of the exchanged rows and flows back through
+        the exchange into the owners' shards"""
+        batch, length = hist.shape
+        ids = torch.cat([hist.reshape(-1), target.reshape(-1)])
+        rows = table_module(ids)
+        pos = torch.arange(batch * (length + 1), device=hist.device, dtype=torch.int64)
+        return rows, pos[:batch * length].view(batch, length), pos[batch * length:]
 
     def _run_sequence(self, hist, target, params):
         self._need_device(hist, target, params[0])
@@ -54,14 +86,14 @@ class DIN(SequenceModel):
     straight into the left half of the fc input, whose right half (t) the gather
     kernel already filled -> fc MLP + sigmoid."""
 
-    def __init__(self, num_items, embed_size):
+    def __init__(self, num_items, embed_size, *, sharded=False, group=None):
         super().__init__()
-        self.item_embedding = nn.Embedding(num_items, embed_size)
+        self.sharded = bool(sharded)
+        self.item_embedding = self._make_table(num_items, embed_size, sharded, group)
         self.attention = nn.Sequential(nn.Linear(embed_size * 3, 128), nn.ReLU(), nn.Linear(128, 64), nn.ReLU(),
                                        nn.Linear(64, 1))
         self.fc = nn.Sequential(nn.Linear(embed_size * 2, 256), nn.ReLU(), nn.Linear(256, 128), nn.ReLU(),
                                 nn.Linear(128, 1), nn.Sigmoid())
-        xavier_normal_(self.item_embedding.weight.data)
 
     def _params(self):
         p = [self.item_embedding.weight]
@@ -71,7 +103,12 @@ class DIN(SequenceModel):
         return p
 
     def forward(self, hist, target_item):
-        return self._run_sequence(hist, target_item, self._params())
+        params = self._params()
+        if self.sharded:
+            self._need_device(hist, target_item, params[0])
+            rows, hist, target_item = self._lookup_sharded(self.item_embedding, hist, target_item)
+            params[0] = rows
+        return self._run_sequence(hist, target_item, params)
 
     def run_forward(self, inputs, params):
         hist, target = inputs
@@ -97,7 +134,7 @@ class DIN(SequenceModel):
         batch, length = hist.shape
         dim = table.shape[1]
         c, fcin = att_acts[0], fc_acts[0]
-        zeros = ops.zero_grads(params)
+        zeros = _zero_grads(self, params)
         fc_grads, gfcin = ops.mlp_bwd(fc_acts, fc, gprob, None, zeros=zeros)
         gscore = torch.empty((batch * length, 1), dtype=torch.float32, device=table.device)
         ops.din_pool_bwd(attn, c, batch, length, dim, gfcin[:, :dim], True, gscore)

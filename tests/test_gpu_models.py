@@ -7,6 +7,8 @@ checked against the CPU oracle on seeded synthetic batches.
 Tolerance (north_star): logits/loss within 1e-5 relative; gradients are sums of
 up to B terms accumulated with fp32 atomics in no fixed order, so they get
 rtol 1e-4 with an absolute floor scaled to the fixture's gradient magnitude."""
+import os
+
 import pytest
 import torch
 
@@ -216,6 +218,79 @@ def test_gradients_of_a_model_share_one_storage_for_the_data_parallel_all_reduce
     assert shared is not None and len(shared) <= GradBucket.MAX_STORAGES
     covered = sum(f.numel() for f in shared)
     assert covered >= sum(p.numel() for p in model.parameters())
+
+
+def _sharded_sequence_worker(rank, world, port, kind, out):
+    # two ranks share the one GPU of the test box; gloo carries the exchange (staged through
+    # the host, dist._host_staged) -- the protocol and every HIP step are the production ones
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from deeplearningrecommendationsystem_amd import synth
+        from deeplearningrecommendationsystem_amd.dist import GradBucket
+        from deeplearningrecommendationsystem_amd.loss import BCELoss
+        from deeplearningrecommendationsystem_amd.model import DIEN, DIN
+        cls = DIN if kind == "din" else DIEN
+        vocab, dim, length, per_rank = 997, 16, 7, 96
+        torch.manual_seed(3)
+        full = cls(vocab, dim).to(DEV)                      # the unsharded model on the GLOBAL batch
+        torch.manual_seed(4)
+        shard = cls(vocab, dim, sharded=True).to(DEV)       # this rank's rows + replicated dense layers
+        sd = full.state_dict()
+        for name, p in shard.named_parameters():
+            if name.endswith("item_embedding.weight"):
+                table = shard.item_embedding if kind == "din" else shard.din.item_embedding
+                table.load_full_table(sd[name])
+            else:
+                p.data.copy_(sd[name])
+        gen = synth.generator(5)
+        hist, target = synth.hist_batch(world * per_rank, length, vocab, gen)
+        y = synth.labels(world * per_rank, True, gen)
+        hist, target, y = hist.to(DEV), target.to(DEV), y.to(DEV)
+        prob_full = full(hist, target)
+        BCELoss()(prob_full, y).backward()
+        mine = slice(rank * per_rank, (rank + 1) * per_rank)
+        prob = shard(hist[mine], target[mine])
+        BCELoss()(prob, y[mine]).backward()
+        GradBucket(shard.parameters()).all_reduce_mean()
+        torch.testing.assert_close(prob, prob_full[mine], rtol=1e-5, atol=1e-6)
+        ref = dict(full.named_parameters())
+        for name, p in shard.named_parameters():
+            want = ref[name].grad
+            if name.endswith("item_embedding.weight"):
+                want = want[rank::world]
+                got = p.grad[:want.shape[0]]
+            else:
+                got = p.grad
+            torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-6, msg=lambda m, n=name: f"{n}: {m}")
+        out.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        out.put((rank, traceback.format_exc()[-1500:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("kind", ["din", "dien"])
+def test_row_sharded_item_table_two_ranks_match_the_unsharded_model(kind):
+    # rows dealt round-robin to the ranks, ids / rows / row gradients exchanged
+    # with all-to-all, dense layers replicated and their gradients averaged
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_sequence_worker, args=(r, 2, port, kind, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    results = dict(out.get(timeout=5) for _ in procs)
+    assert results == {0: "ok", 1: "ok"}, results
 
 
 def test_trainer_mirror_trains_neuralcf_eager_and_graphed():
