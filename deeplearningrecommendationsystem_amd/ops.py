@@ -361,7 +361,12 @@ def mlp_bwd(acts: Sequence[torch.Tensor], layers: Sequence[Layer], gy: torch.Ten
         arr = _mlp_layer_array(layers, acts[1:], grads)
         ws = _scratch(x0.device)
         dims = [(layer.weight.shape[0], layer.weight.shape[1]) for layer in layers]
-        rc = _timed("mlp_fused_bwd", lambda: (4 * m * (2 * dims[0][1] + 2 * sum(n for n, _ in dims)),
+        # algorithmic bytes: x and every intermediate Y read once (as the next layer's input; the
+        # activation mask is folded into the dX write-back), gY read, the last Y only when it has an
+        # activation to mask, gX written
+        last_mask = dims[-1][0] if layers[-1].act != ACT_NONE else 0
+        rc = _timed("mlp_fused_bwd", lambda: (4 * m * (dims[0][1] + sum(n for n, _ in dims[:-1]) + dims[-1][0] +
+                                                       last_mask + (dims[0][1] if gx is not None else 0)),
                                               4 * m * sum(n * k for n, k in dims)),
                     _lib.load().ctr_mlp_bwd, x0.data_ptr(), _ld(x0), m, arr, len(layers), gy.data_ptr(), _ld(gy),
                     _lib.ptr(gx), _ld(gx) if gx is not None else 0, ws.data_ptr(), ws.numel(), _lib.stream_ptr())

@@ -1,6 +1,6 @@
 #!/bin/bash
 # end-of-round evidence: GPU tests, default bench line, rocprofv3 kernel stats of the same command, PMC traffic
-R=$PWD
+R=$PWD; rm -rf gpurun_out/r01_prof gpurun_out/traffic_FETCH_SIZE gpurun_out/traffic_WRITE_SIZE
 python -m pytest tests -q -m gpu 2>&1 | tail -2 | tee gpurun_out/r01_gpu_tests.txt
 python bench.py > gpurun_out/r01_bench_neuralcf.json 2>gpurun_out/r01_bench.err; tail -c 1500 gpurun_out/r01_bench_neuralcf.json
 cd /tmp && export TMPDIR=/tmp
