@@ -116,6 +116,10 @@ bool ctr_n1_supported(int k);
 int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch,
                          const float* gout, int64_t ldo, float* workspace, int64_t workspace_floats,
                          int64_t* used_floats, unsigned char* handled, hipStream_t st);
+// embed_bag.hip: bag-table gradients by register accumulation per output column (see there)
+int ctr_embed_bwd_bags(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch,
+                       const float* gout, int64_t ldo, float* workspace, int64_t workspace_floats,
+                       int64_t* used_floats, unsigned char* handled, hipStream_t st);
 int ctr_n1_fwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* res, int64_t ldr, float* y,
                int64_t ldy, int64_t m, int k, int act, hipStream_t st);
 int ctr_n1_bwd(const float* x, int64_t ldx, const float* w, const float* y, int64_t ldy, const float* gy, int64_t ldgy,

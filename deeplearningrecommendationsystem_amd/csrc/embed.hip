@@ -430,10 +430,17 @@ extern "C" int ctr_embed_bwd(const ctr_field_t* fields, int nfields, const float
   // small tables under a large batch: bucket the samples by row and reduce runs in
   // registers (embed_sorted.hip); what it takes is dropped from the scatter launch below
   unsigned char handled[CTR_MAX_FIELDS];
-  int64_t sort_floats = 0;
+  int64_t sort_floats = 0, bag_floats_used = 0;
   rc = ctr_embed_bwd_sorted(fields, nfields, x, ldx, batch, gout, ldo, workspace, workspace_floats, &sort_floats,
                             handled, st);
   if (rc != CTR_OK) return rc;
+  workspace_floats -= sort_floats;  // the sort buffers sit at the end
+  // bag tables: register accumulation per output column (embed_bag.hip), partials at the start
+  rc = ctr_embed_bwd_bags(fields, nfields, x, ldx, batch, gout, ldo, workspace, workspace_floats, &bag_floats_used,
+                          handled, st);
+  if (rc != CTR_OK) return rc;
+  if (workspace) workspace += bag_floats_used;
+  workspace_floats -= bag_floats_used;
   ctr_field_t rest[CTR_MAX_FIELDS];
   int nrest = 0;
   for (int i = 0; i < nfields; ++i) {
@@ -444,7 +451,6 @@ extern "C" int ctr_embed_bwd(const ctr_field_t* fields, int nfields, const float
   if (nrest == 0) return CTR_OK;
   fields = rest;
   nfields = nrest;
-  workspace_floats -= sort_floats;
   rc = make_plan(fields, nfields, x, ldx, gout, ldo, true, &plan);
   if (rc != CTR_OK) return rc;
   CTR_REQUIRE(batch * plan.units < (1ll << 32), CTR_ELIMIT);
