@@ -77,6 +77,13 @@ struct NcfShape {  // model/neuralcf.py:23-27 at BASELINE configs[1]: 128 -> 64 
   static constexpr int K[5] = {128, 64, 32, 16, 8};
   static constexpr int ACT[5] = {CTR_ACT_RELU, CTR_ACT_RELU, CTR_ACT_RELU, CTR_ACT_RELU, CTR_ACT_NONE};
 };
+struct DienAttShape {  // model/dien.py:13-19 at BASELINE configs[4] (E = 16): 48 -> 64 -> 32 -> 1
+  static constexpr bool kFixed = true;
+  static constexpr int kLayers = 3;
+  static constexpr int N[3] = {64, 32, 1};
+  static constexpr int K[3] = {48, 64, 32};
+  static constexpr int ACT[3] = {CTR_ACT_RELU, CTR_ACT_RELU, CTR_ACT_NONE};
+};
 
 template <class F, int... I>
 __device__ __forceinline__ void static_layers(F& f, std::integer_sequence<int, I...>) {
@@ -917,6 +924,11 @@ extern "C" int ctr_mlp_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp
     if (rc != CTR_OK) return rc;
     hipLaunchKernelGGL(mlp_fwd_kernel<NcfShape>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, (hipStream_t)stream,
                        b.d, x, ldx, m);
+  } else if (matches<DienAttShape, false>(layers, nlayers, b.d)) {
+    rc = allow_lds(mlp_fwd_kernel<DienAttShape>, b.lds_bytes);
+    if (rc != CTR_OK) return rc;
+    hipLaunchKernelGGL(mlp_fwd_kernel<DienAttShape>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes,
+                       (hipStream_t)stream, b.d, x, ldx, m);
   } else {
     rc = allow_lds(mlp_fwd_kernel<DynShape>, b.lds_bytes);
     if (rc != CTR_OK) return rc;
@@ -952,6 +964,7 @@ extern "C" int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp
                        m, gy, ldgy, gx, ldgx, workspace, b.slab);                                                  \
   } while (0)
   if (matches<NcfShape, true>(layers, nlayers, b.d)) CTR_LAUNCH_BWD(NcfShape, 14);
+  else if (matches<DienAttShape, true>(layers, nlayers, b.d)) CTR_LAUNCH_BWD(DienAttShape, 8);
   else if (maxt == 8) CTR_LAUNCH_BWD(DynShape, 8);
   else if (maxt == 12) CTR_LAUNCH_BWD(DynShape, 12);
   else if (maxt == 14) CTR_LAUNCH_BWD(DynShape, 14);
