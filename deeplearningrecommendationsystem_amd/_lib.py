@@ -15,7 +15,8 @@ import torch  # noqa: F401  (maps libamdhip64 first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTRHIP_LIB", os.path.join(_HERE, "libctrhip.so"))  # env override: A/B builds
-ABI_VERSION = 5
+ABI_VERSION = 6
+DIN_TRIPLE, DIN_PAIR = 0, 1  # layouts of the DIN attention operand (include/ctrhip.h)
 
 CTR_MAX_FIELDS = 32
 FIELD_ID_I64, FIELD_ID_F32, FIELD_BAG, FIELD_DENSE, FIELD_PROD_I64 = range(5)
@@ -70,10 +71,10 @@ SIGNATURES = {
     "ctr_ffm_head_bwd": (_i, [_p, _l, _l, _i, _i, C.POINTER(C.c_int32), _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l,
                               _p, _p, _p, _l, _p, _l, _p, _p, _p, _p, _p, _l, _p, _l, _p]),
     "ctr_act_bwd": (_i, [_p, _l, _p, _l, _p, _l, _l, _i, _i, _i, _p]),
-    "ctr_din_concat_fwd": (_i, [_p, _l, _i, _p, _p, _l, _i, _p, _l, _p, _l, _p, _p]),
+    "ctr_din_concat_fwd": (_i, [_p, _l, _i, _p, _p, _l, _i, _p, _l, _p, _l, _i, _p, _p]),
     "ctr_din_pool_fwd": (_i, [_p, _p, _l, _l, _i, _i, _p, _p, _l, _i, _p]),
     "ctr_din_pool_bwd": (_i, [_p, _p, _l, _l, _i, _i, _p, _l, _i, _p, _p]),
-    "ctr_din_concat_bwd": (_i, [_p, _p, _l, _l, _i, _i, _p, _l, _p, _p, _l, _i, _p, _l, _p, _p]),
+    "ctr_din_concat_bwd": (_i, [_p, _p, _l, _l, _i, _i, _p, _l, _p, _p, _l, _i, _p, _l, _i, _p, _p]),
     "ctr_gru_fwd": (_i, [_p, _l, _p, _p, _l, _i, _i, _p, _p, _l, _p]),
     "ctr_gru_bwd": (_i, [_p, _l, _p, _p, _p, _l, _i, _i, _p, _l, _p, _p, _p]),
     "ctr_mlp_fwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, _p]),

@@ -68,12 +68,13 @@ __device__ __forceinline__ int64_t safe_row(int64_t r, int64_t vocab, int32_t* e
   return r;
 }
 
-// c[(b*L+l), 0:E] = h, [E:2E] = h - t, [2E:3E] = t ; tvec[b, 0:E] = t
+// triple: c[(b*L+l), 0:E] = h, [E:2E] = h - t, [2E:3E] = t ; pair: [0:E] = h, [E:2E] = t ;
+// tvec[b, 0:E] = t
 template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 concat_fwd_kernel(const SeqGeom g, const float* __restrict__ table, int64_t vocab, const int64_t* __restrict__ hist,
                   const int64_t* __restrict__ target, float* __restrict__ c, int64_t ldc, float* __restrict__ tvec,
-                  int64_t ldt, int32_t* err) {
+                  int64_t ldt, int32_t* err, int pair) {
   const int sub = threadIdx.x % g.lpr;
   const int64_t rows = g.batch * g.len;
   const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / g.lpr;
@@ -90,8 +91,12 @@ concat_fwd_kernel(const SeqGeom g, const float* __restrict__ table, int64_t voca
       for (int v = 0; v < VEC; ++v) d.v[v] = h.v[v] - t.v[v];
       float* dst = c + row * ldc + e;
       h.store(dst);
-      d.store(dst + g.dim);
-      t.store(dst + 2 * g.dim);
+      if (pair) {
+        t.store(dst + g.dim);
+      } else {
+        d.store(dst + g.dim);
+        t.store(dst + 2 * g.dim);
+      }
       if (l == 0 && tvec) t.store(tvec + b * ldt + e);
     }
   }
@@ -225,7 +230,7 @@ __global__ void __launch_bounds__(kBlock)
 concat_bwd_kernel(const SeqGeom g, const int64_t* __restrict__ hist, const int64_t* __restrict__ target,
                   int64_t vocab, const float* __restrict__ gc, int64_t ldc, const float* __restrict__ attn,
                   const float* __restrict__ gout, int64_t ldgo, int summed, const float* __restrict__ gt_extra,
-                  int64_t ldgt, float* __restrict__ gtable) {
+                  int64_t ldgt, float* __restrict__ gtable, int pair) {
   extern __shared__ float s_pad[];  // E floats: gradient of row 0 accumulated by this workgroup
   for (int i = threadIdx.x; i < g.dim; i += blockDim.x) s_pad[i] = 0.0f;
   __syncthreads();
@@ -255,12 +260,13 @@ concat_bwd_kernel(const SeqGeom g, const int64_t* __restrict__ hist, const int64
             Pack<VEC> g1, g2, g3, go;
             g1.load(gcr + e);
             g2.load(gcr + g.dim + e);
-            g3.load(gcr + 2 * g.dim + e);
+            if (!pair) g3.load(gcr + 2 * g.dim + e);
             go.load(gr + e);
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-              const float gh = (g1.v[v] + g2.v[v]) + al * go.v[v];
-              tacc[q][v] += g3.v[v] - g2.v[v];
+              // pair layout [gh, gt]: the h - t column was folded into the weights upstream
+              const float gh = pair ? g1.v[v] + al * go.v[v] : (g1.v[v] + g2.v[v]) + al * go.v[v];
+              tacc[q][v] += pair ? g2.v[v] : g3.v[v] - g2.v[v];
               if (hr == 0)
                 atomicAdd(s_pad + e + v, gh);
               else
@@ -309,10 +315,12 @@ inline int check_dim(const SeqGeom& g) {
 
 extern "C" int ctr_din_concat_fwd(const float* table, int64_t vocab, int dim, const int64_t* hist,
                                   const int64_t* target, int64_t batch, int len, float* c, int64_t ldc, float* tvec,
-                                  int64_t ldt, int32_t* err_flag, void* stream) {
+                                  int64_t ldt, int layout, int32_t* err_flag, void* stream) {
   CTR_REQUIRE(batch >= 0 && len >= 0, CTR_EINVAL);
   if (batch == 0 || len == 0) return CTR_OK;
-  CTR_REQUIRE(table && hist && target && c && vocab > 0 && dim > 0 && ldc >= 3 * (int64_t)dim, CTR_EINVAL);
+  CTR_REQUIRE(layout == CTR_DIN_TRIPLE || layout == CTR_DIN_PAIR, CTR_EINVAL);
+  const int pair = layout == CTR_DIN_PAIR;
+  CTR_REQUIRE(table && hist && target && c && vocab > 0 && dim > 0 && ldc >= (pair ? 2 : 3) * (int64_t)dim, CTR_EINVAL);
   CTR_REQUIRE(!tvec || ldt >= dim, CTR_EINVAL);
   const bool al = ctr_aligned16(table) && ctr_aligned16(c) && ldc % 4 == 0 && (!tvec || (ctr_aligned16(tvec) && ldt % 4 == 0));
   const SeqGeom g = make_geom(batch, len, dim, al);
@@ -320,10 +328,10 @@ extern "C" int ctr_din_concat_fwd(const float* table, int64_t vocab, int dim, co
   hipStream_t st = (hipStream_t)stream;
   if (g.vec == 4)
     hipLaunchKernelGGL(concat_fwd_kernel<4>, dim3(grid), dim3(kBlock), 0, st, g, table, vocab, hist, target, c, ldc,
-                       tvec, ldt, err_flag);
+                       tvec, ldt, err_flag, pair);
   else
     hipLaunchKernelGGL(concat_fwd_kernel<1>, dim3(grid), dim3(kBlock), 0, st, g, table, vocab, hist, target, c, ldc,
-                       tvec, ldt, err_flag);
+                       tvec, ldt, err_flag, pair);
   return ctr_launch_status();
 }
 
@@ -365,12 +373,14 @@ extern "C" int ctr_din_pool_bwd(const float* attn, const float* hsrc, int64_t ld
 
 extern "C" int ctr_din_concat_bwd(const int64_t* hist, const int64_t* target, int64_t vocab, int64_t batch, int len,
                                   int dim, const float* gc, int64_t ldc, const float* attn, const float* gout,
-                                  int64_t ldgo, int summed, const float* gt_extra, int64_t ldgt, float* gtable,
-                                  void* stream) {
+                                  int64_t ldgo, int summed, const float* gt_extra, int64_t ldgt, int layout,
+                                  float* gtable, void* stream) {
   CTR_REQUIRE(batch >= 0 && len >= 0, CTR_EINVAL);
   if (batch == 0 || len == 0) return CTR_OK;
+  CTR_REQUIRE(layout == CTR_DIN_TRIPLE || layout == CTR_DIN_PAIR, CTR_EINVAL);
+  const int pair = layout == CTR_DIN_PAIR;
   CTR_REQUIRE(hist && target && gc && attn && gout && gtable && vocab > 0 && dim > 0, CTR_EINVAL);
-  CTR_REQUIRE(ldc >= 3 * (int64_t)dim && ldgo >= dim && (!gt_extra || ldgt >= dim), CTR_EINVAL);
+  CTR_REQUIRE(ldc >= (pair ? 2 : 3) * (int64_t)dim && ldgo >= dim && (!gt_extra || ldgt >= dim), CTR_EINVAL);
   // one dword per lane: a wave's atomic instruction then adds to contiguous runs of a gradient
   // row (256 B for E >= 64), the shape that runs at the full memory-side atomic rate --
   // dwordx4 per lane strides the lanes 16 B apart and measured 3x slower on the row scatter
@@ -383,9 +393,9 @@ extern "C" int ctr_din_concat_bwd(const int64_t* hist, const int64_t* target, in
   const size_t dyn = (size_t)dim * sizeof(float);
   if (g.vec == 4)
     hipLaunchKernelGGL(concat_bwd_kernel<4>, dim3(grid), dim3(kBlock), dyn, st, g, hist, target, vocab, gc, ldc, attn,
-                       gout, ldgo, summed, gt_extra, ldgt, gtable);
+                       gout, ldgo, summed, gt_extra, ldgt, gtable, pair);
   else
     hipLaunchKernelGGL(concat_bwd_kernel<1>, dim3(grid), dim3(kBlock), dyn, st, g, hist, target, vocab, gc, ldc, attn,
-                       gout, ldgo, summed, gt_extra, ldgt, gtable);
+                       gout, ldgo, summed, gt_extra, ldgt, gtable, pair);
   return ctr_launch_status();
 }

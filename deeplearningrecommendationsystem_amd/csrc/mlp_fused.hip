@@ -77,11 +77,11 @@ struct NcfShape {  // model/neuralcf.py:23-27 at BASELINE configs[1]: 128 -> 64 
   static constexpr int K[5] = {128, 64, 32, 16, 8};
   static constexpr int ACT[5] = {CTR_ACT_RELU, CTR_ACT_RELU, CTR_ACT_RELU, CTR_ACT_RELU, CTR_ACT_NONE};
 };
-struct DienAttShape {  // model/dien.py:13-19 at BASELINE configs[4] (E = 16): 48 -> 64 -> 32 -> 1
+struct DienAttShape {  // model/dien.py:13-19 at BASELINE configs[4] (E = 16) on the folded [h, t] operand: 32 -> 64 -> 32 -> 1
   static constexpr bool kFixed = true;
   static constexpr int kLayers = 3;
   static constexpr int N[3] = {64, 32, 1};
-  static constexpr int K[3] = {48, 64, 32};
+  static constexpr int K[3] = {32, 64, 32};
   static constexpr int ACT[3] = {CTR_ACT_RELU, CTR_ACT_RELU, CTR_ACT_NONE};
 };
 

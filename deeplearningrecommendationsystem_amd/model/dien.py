@@ -7,7 +7,8 @@ from torch.nn.init import xavier_normal_
 
 from .. import ops
 from ..ops import ACT_NONE, Layer
-from .din import SequenceModel, _zero_grads, attention_layers, fc_layers
+from .din import (SequenceModel, _zero_grads, attention_layers, fc_layers, fold_attention_weight,
+                  unfold_attention_grad)
 
 
 class DIN(nn.Module):
@@ -65,9 +66,11 @@ class DIEN(SequenceModel):
         batch, length = hist.shape
         dim = table.shape[1]
         dev = table.device
-        c = torch.empty((batch * length, 3 * dim), dtype=torch.float32, device=dev)
+        w1f = fold_attention_weight(att[0].weight, dim)  # [h, t] operand instead of [h, h-t, t]
+        att[0] = Layer(w1f, att[0].bias, att[0].act)
+        c = torch.empty((batch * length, 2 * dim), dtype=torch.float32, device=dev)
         fcin = torch.empty((batch, 2 * dim), dtype=torch.float32, device=dev)
-        ops.din_concat_fwd(table, hist, target, c, fcin[:, dim:], self._flag)
+        ops.din_concat_fwd(table, hist, target, c, fcin[:, dim:], self._flag, pair=True)
         att_acts = ops.mlp_fwd(c, att)
         attn = torch.empty((batch, length), dtype=torch.float32, device=dev)
         seq = torch.empty((batch * length, dim), dtype=torch.float32, device=dev)
@@ -76,19 +79,22 @@ class DIEN(SequenceModel):
         hbuf = torch.empty((batch * (length + 1), dim), dtype=torch.float32, device=dev)
         ops.gru_fwd(gi, w_hh, b_hh, batch, length, dim, hbuf, fcin[:, :dim])
         fc_acts = ops.mlp_fwd(fcin, fc)
-        return fc_acts[-1], (att_acts, attn, seq, gi, hbuf, fc_acts)
+        return fc_acts[-1], (att_acts, attn, seq, gi, hbuf, fc_acts, w1f)
 
     def run_backward(self, state, inputs, params, gprob):
         hist, target = inputs
-        att_acts, attn, seq, gi, hbuf, fc_acts = state
+        att_acts, attn, seq, gi, hbuf, fc_acts, w1f = state
         table = params[0]
         att, fc = attention_layers(params[1:7]), fc_layers(params[7:13])
+        w1 = att[0].weight
+        att[0] = Layer(w1f, att[0].bias, att[0].act)
         w_ih, w_hh, b_ih, b_hh = params[13:17]
         batch, length = hist.shape
         dim = table.shape[1]
         dev = table.device
         c = att_acts[0]
         zeros = _zero_grads(self, params)
+        zeros[id(w1f)] = torch.zeros_like(w1f)
         fc_grads, gfcin = ops.mlp_bwd(fc_acts, fc, gprob, None, zeros=zeros)
         dgi = torch.empty((batch * length, 3 * dim), dtype=torch.float32, device=dev)
         dgh = torch.empty((batch * (length + 1), 3 * dim), dtype=torch.float32, device=dev)
@@ -105,7 +111,10 @@ class DIEN(SequenceModel):
         ops.din_pool_bwd(attn, c, batch, length, dim, gseq, False, gscore)
         att_grads, gc = ops.mlp_bwd(att_acts, att, gscore, None, zeros=zeros)
         gtable = zeros[id(table)]
-        ops.din_concat_bwd(hist, target, table.shape[0], dim, gc, attn, gseq, False, gfcin[:, dim:], gtable)
+        ops.din_concat_bwd(hist, target, table.shape[0], dim, gc, attn, gseq, False, gfcin[:, dim:], gtable,
+                           pair=True)
+        unfold_attention_grad(att_grads[0][0], zeros[id(w1)], dim)
+        att_grads[0] = (zeros[id(w1)], att_grads[0][1])
         grads = [gtable]
         for gw, gb in att_grads + fc_grads:
             grads += [gw, gb]

@@ -16,6 +16,25 @@ def attention_layers(p):
     return [Layer(p[0], p[1], ACT_RELU), Layer(p[2], p[3], ACT_RELU), Layer(p[4], p[5], ACT_NONE)]
 
 
+def fold_attention_weight(w1, dim):
+    """``W1 @ [h, h-t, t] == [Wa+Wb, Wc-Wb] @ [h, t]`` (W1 = [Wa | Wb | Wc], model/din.py:39-42):
+    the first attention layer on a 2E-wide operand instead of the reference's 3E -- two thirds
+    of the bytes and flops of the largest GEMM of a step, same layer output up to fp32 rounding.
+    Returns the folded (n, 2E) weight (two small elementwise launches)."""
+    folded = torch.empty((w1.shape[0], 2 * dim), dtype=w1.dtype, device=w1.device)
+    torch.add(w1[:, :dim], w1[:, dim:2 * dim], out=folded[:, :dim])
+    torch.sub(w1[:, 2 * dim:], w1[:, dim:2 * dim], out=folded[:, dim:])
+    return folded
+
+
+def unfold_attention_grad(gfolded, gw1, dim):
+    """chain rule of ``fold_attention_weight``: dWa = g1, dWb = g1 - g2, dWc = g2"""
+    g1, g2 = gfolded[:, :dim], gfolded[:, dim:]
+    gw1[:, :dim].copy_(g1)
+    torch.sub(g1, g2, out=gw1[:, dim:2 * dim])
+    gw1[:, 2 * dim:].copy_(g2)
+
+
 def fc_layers(p):
     return [Layer(p[0], p[1], ACT_RELU), Layer(p[2], p[3], ACT_RELU), Layer(p[4], p[5], ACT_SIGMOID)]
 
@@ -117,30 +136,38 @@ class DIN(SequenceModel):
         batch, length = hist.shape
         dim = table.shape[1]
         dev = table.device
-        c = torch.empty((batch * length, 3 * dim), dtype=torch.float32, device=dev)
+        w1f = fold_attention_weight(att[0].weight, dim)
+        att[0] = Layer(w1f, att[0].bias, att[0].act)
+        c = torch.empty((batch * length, 2 * dim), dtype=torch.float32, device=dev)
         fcin = torch.empty((batch, 2 * dim), dtype=torch.float32, device=dev)
-        ops.din_concat_fwd(table, hist, target, c, fcin[:, dim:], self._flag)
+        ops.din_concat_fwd(table, hist, target, c, fcin[:, dim:], self._flag, pair=True)
         att_acts = ops.mlp_fwd(c, att)
         attn = torch.empty((batch, length), dtype=torch.float32, device=dev)
         ops.din_pool_fwd(att_acts[-1], c, batch, length, dim, attn, fcin[:, :dim], summed=True)
         fc_acts = ops.mlp_fwd(fcin, fc)
-        return fc_acts[-1], (att_acts, attn, fc_acts)
+        return fc_acts[-1], (att_acts, attn, fc_acts, w1f)
 
     def run_backward(self, state, inputs, params, gprob):
         hist, target = inputs
-        att_acts, attn, fc_acts = state
+        att_acts, attn, fc_acts, w1f = state
         table = params[0]
         att, fc = attention_layers(params[1:7]), fc_layers(params[7:13])
+        w1 = att[0].weight
+        att[0] = Layer(w1f, att[0].bias, att[0].act)
         batch, length = hist.shape
         dim = table.shape[1]
         c, fcin = att_acts[0], fc_acts[0]
         zeros = _zero_grads(self, params)
+        zeros[id(w1f)] = torch.zeros_like(w1f)
         fc_grads, gfcin = ops.mlp_bwd(fc_acts, fc, gprob, None, zeros=zeros)
         gscore = torch.empty((batch * length, 1), dtype=torch.float32, device=table.device)
         ops.din_pool_bwd(attn, c, batch, length, dim, gfcin[:, :dim], True, gscore)
         att_grads, gc = ops.mlp_bwd(att_acts, att, gscore, None, zeros=zeros)
         gtable = zeros[id(table)]
-        ops.din_concat_bwd(hist, target, table.shape[0], dim, gc, attn, gfcin[:, :dim], True, gfcin[:, dim:], gtable)
+        ops.din_concat_bwd(hist, target, table.shape[0], dim, gc, attn, gfcin[:, :dim], True, gfcin[:, dim:], gtable,
+                           pair=True)
+        unfold_attention_grad(att_grads[0][0], zeros[id(w1)], dim)
+        att_grads[0] = (zeros[id(w1)], att_grads[0][1])
         grads = [gtable]
         for gw, gb in att_grads + fc_grads:
             grads += [gw, gb]

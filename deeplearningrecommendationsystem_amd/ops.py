@@ -496,15 +496,18 @@ def act_bwd(y, gy, act: int, out, accumulate: bool) -> None:
 # ---------------------------------------------------------------------------
 # DIN / DIEN sequence attention and GRU
 # ---------------------------------------------------------------------------
-def din_concat_fwd(table, hist, target, c, tvec, err_flag=None) -> None:
+def din_concat_fwd(table, hist, target, c, tvec, err_flag=None, pair: bool = False) -> None:
+    """attention operand per position: [h, h-t, t] (the reference's cat) or, ``pair``, [h, t]"""
     _lib.require_device(table, hist, target)
     c = _mat(c, "c")
     batch, length = hist.shape
     dim = table.shape[1]
-    rc = _timed("din_concat_fwd", lambda: (batch * length * (dim * 4 + 8 + 12 * dim) + batch * (8 + 8 * dim), 0),
+    width = 2 if pair else 3
+    rc = _timed("din_concat_fwd", lambda: (batch * length * (dim * 4 + 8 + 4 * width * dim) + batch * (8 + 8 * dim), 0),
                 _lib.load().ctr_din_concat_fwd, table.data_ptr(), table.shape[0], dim, hist.data_ptr(),
                 target.data_ptr(), batch, length, c.data_ptr(), _ld(c), _lib.ptr(tvec),
-                _ld(tvec) if tvec is not None else 0, _lib.ptr(err_flag), _lib.stream_ptr())
+                _ld(tvec) if tvec is not None else 0, _lib.DIN_PAIR if pair else _lib.DIN_TRIPLE,
+                _lib.ptr(err_flag), _lib.stream_ptr())
     _lib.check(rc, "ctr_din_concat_fwd")
 
 
@@ -524,14 +527,16 @@ def din_pool_bwd(attn, hsrc, batch, length, dim, gout, summed: bool, gscore) -> 
     _lib.check(rc, "ctr_din_pool_bwd")
 
 
-def din_concat_bwd(hist, target, vocab, dim, gc, attn, gout, summed: bool, gt_extra, gtable) -> None:
+def din_concat_bwd(hist, target, vocab, dim, gc, attn, gout, summed: bool, gt_extra, gtable,
+                   pair: bool = False) -> None:
     gc, gout = _mat(gc, "gc"), _mat(gout, "gout")
     batch, length = hist.shape
-    rc = _timed("din_concat_bwd", lambda: (batch * length * (8 + 4 + 12 * dim + 8 * dim) + batch * 16 * dim, 0),
+    width = 2 if pair else 3
+    rc = _timed("din_concat_bwd", lambda: (batch * length * (8 + 4 + 4 * width * dim + 8 * dim) + batch * 16 * dim, 0),
                 _lib.load().ctr_din_concat_bwd, hist.data_ptr(), target.data_ptr(), vocab, batch, length, dim,
                 gc.data_ptr(), _ld(gc), attn.data_ptr(), gout.data_ptr(), _ld(gout), int(summed),
-                _lib.ptr(gt_extra), _ld(gt_extra) if gt_extra is not None else 0, gtable.data_ptr(),
-                _lib.stream_ptr())
+                _lib.ptr(gt_extra), _ld(gt_extra) if gt_extra is not None else 0,
+                _lib.DIN_PAIR if pair else _lib.DIN_TRIPLE, gtable.data_ptr(), _lib.stream_ptr())
     _lib.check(rc, "ctr_din_concat_bwd")
 
 

@@ -198,10 +198,15 @@ int ctr_act_bwd(const float* y, int64_t ldy, const float* gy, int64_t ldgy, floa
  * ---------------------------------------------------------------------- */
 
 /* K3 sequence gather fused with the attention operand (din.py:35-42):
- *   c[(b*len+l)*ldc + 0:E] = h, [E:2E] = h - t, [2E:3E] = t,  h = table[hist[b,l]],
- *   t = table[target[b]];  tvec[b*ldt + 0:E] = t  (tvec may be NULL). */
+ *   CTR_DIN_TRIPLE: c[(b*len+l)*ldc + 0:E] = h, [E:2E] = h - t, [2E:3E] = t   (the reference's cat)
+ *   CTR_DIN_PAIR:   c[(b*len+l)*ldc + 0:E] = h, [E:2E] = t.  Since W.[h, h-t, t] =
+ *                   (Wa+Wb).h + (Wc-Wb).t, a caller that folds the first attention layer's weight
+ *                   columns this way gets the same layer output from a 2E-wide operand (2/3 of
+ *                   the bytes and flops of the largest GEMM of the step).
+ *   h = table[hist[b,l]], t = table[target[b]];  tvec[b*ldt + 0:E] = t  (tvec may be NULL). */
+enum { CTR_DIN_TRIPLE = 0, CTR_DIN_PAIR = 1 };
 int ctr_din_concat_fwd(const float* table, int64_t vocab, int dim, const int64_t* hist, const int64_t* target,
-                       int64_t batch, int len, float* c, int64_t ldc, float* tvec, int64_t ldt,
+                       int64_t batch, int len, float* c, int64_t ldc, float* tvec, int64_t ldt, int layout,
                        int32_t* err_flag, void* stream);
 /* attn[b,:] = softmax_len(score[b,:]) with no padding mask (din.py:44); h_l is read
  * from hsrc[(b*len+l)*ldh ...].  summed != 0: out[b*ldo ...] = sum_l attn_l h_l
@@ -212,11 +217,13 @@ int ctr_din_pool_fwd(const float* score, const float* hsrc, int64_t ldh, int64_t
 int ctr_din_pool_bwd(const float* attn, const float* hsrc, int64_t ldh, int64_t batch, int len, int dim,
                      const float* gout, int64_t ldgo, int summed, float* gscore, void* stream);
 /* every gradient path into the dense item-table gradient (+=, fp32 atomics):
- *   row hist[b,l]  += gc[.,0:E] + gc[.,E:2E] + attn[b,l] * gout_l
- *   row target[b]  += sum_l (gc[.,2E:3E] - gc[.,E:2E]) + gt_extra[b]   (gt_extra may be NULL) */
+ *   CTR_DIN_TRIPLE: row hist[b,l] += gc[.,0:E] + gc[.,E:2E] + attn[b,l] * gout_l
+ *                   row target[b] += sum_l (gc[.,2E:3E] - gc[.,E:2E]) + gt_extra[b]
+ *   CTR_DIN_PAIR:   row hist[b,l] += gc[.,0:E] + attn[b,l] * gout_l
+ *                   row target[b] += sum_l gc[.,E:2E] + gt_extra[b]          (gt_extra may be NULL) */
 int ctr_din_concat_bwd(const int64_t* hist, const int64_t* target, int64_t vocab, int64_t batch, int len, int dim,
                        const float* gc, int64_t ldc, const float* attn, const float* gout, int64_t ldgo,
-                       int summed, const float* gt_extra, int64_t ldgt, float* gtable, void* stream);
+                       int summed, const float* gt_extra, int64_t ldgt, int layout, float* gtable, void* stream);
 
 /* ------------------------------------------------------------------------
  * DIEN interest evolution: nn.GRU(E, E, batch_first=True), one layer, h0 = 0
