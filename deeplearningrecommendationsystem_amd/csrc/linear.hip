@@ -218,7 +218,7 @@ __device__ __forceinline__ void read_frag(const float* lds, int r, int h, float 
 }
 
 template <int NT, int AMODE, int BMODE, class ASrc, class BSrc, class Epi>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads, 2)  /* two waves per SIMD: the 2 workgroups per CU the LDS allows */
 gemm_tile_kernel(const ASrc a, const BSrc b, const Epi epi, int64_t M, int N, int64_t K, int64_t k_chunk,
                  float* __restrict__ bias_grad /* dW pass only: column sums of A */,
                  int64_t bias_slab_stride /* 0: atomics into bias_grad, else slab z of it */) {
@@ -230,27 +230,24 @@ gemm_tile_kernel(const ASrc a, const BSrc b, const Epi epi, int64_t M, int N, in
   __shared__ __attribute__((aligned(16))) float s_a[2][AStage::kLdsFloats];
   __shared__ __attribute__((aligned(16))) float s_b[2][BStage::kLdsFloats];
 
-  const int64_t i0 = (int64_t)blockIdx.x * kBM;
+  // Persistent over the M tiles: workgroup x walks tiles x, x + gridDim.x, ... and the
+  // global-load / LDS-store / MFMA pipeline runs straight across tile boundaries, so only
+  // the very first tile pays an exposed load latency and every epilogue overlaps the loads
+  // of the next tile.  With short contractions (k = 128: four steps per tile) the per-tile
+  // prologue used to cost more than the MFMAs.
+  const int64_t mtiles = (M + kBM - 1) / kBM;
   const int64_t j0 = (int64_t)blockIdx.y * BN;
   const int64_t kb = (int64_t)blockIdx.z * k_chunk;
   const int64_t ke = kb + k_chunk < K ? kb + k_chunk : K;
   const int nk = (int)((ke - kb + kBK - 1) / kBK);
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 31, h = lane >> 5;
+  const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
   // Four independent accumulator chains per wave whatever NT is: consecutive MFMAs never
   // wait on each other's result.  NT = 4: one chain per column tile; NT = 2 / 1: the
   // contraction steps are dealt round-robin to 2 / 4 chains per tile, summed at the end.
   constexpr int CH = 4 / NT;
   floatx16 acc[NT][CH];
-#pragma unroll
-  for (int n = 0; n < NT; ++n)
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[n][c][e] = 0.0f;
-  float colsum = 0.0f;
 
   // aligned operands take the branch-free predicated load path for every tile
   const bool a_in = a.fast_ok();
@@ -258,69 +255,101 @@ gemm_tile_kernel(const ASrc a, const BSrc b, const Epi epi, int64_t M, int N, in
 
   AStage sa;
   BStage sb;
-  sa.load(a, i0, kb, a_in);
+  int64_t tile = blockIdx.x;
+  if (tile >= mtiles || nk <= 0) return;
+  // (tile, step) of the pipeline slot one / two steps ahead of the one being multiplied
+  auto advance = [&](int64_t& t, int& k) {
+    if (++k == nk) {
+      k = 0;
+      t += gridDim.x;
+    }
+  };
+  int64_t t1 = tile, t2 = tile;
+  int k1 = 0, k2 = 0;
+  advance(t1, k1);
+  t2 = t1;
+  k2 = k1;
+  advance(t2, k2);
+  sa.load(a, tile * kBM, kb, a_in);
   sb.load(b, j0, kb, b_in);
   sa.store(s_a[0]);
   sb.store(s_b[0]);
-  if (nk > 1) {
-    sa.load(a, i0, kb + kBK, a_in);
-    sb.load(b, j0, kb + kBK, b_in);
+  if (t1 < mtiles) {
+    sa.load(a, t1 * kBM, kb + (int64_t)k1 * kBK, a_in);
+    sb.load(b, j0, kb + (int64_t)k1 * kBK, b_in);
   }
   __syncthreads();
-  for (int ks = 0; ks < nk; ++ks) {
-    const int cur = ks & 1;
-    if (ks + 1 < nk) {
-      sa.store(s_a[cur ^ 1]);
-      sb.store(s_b[cur ^ 1]);
-    }
-    if (ks + 2 < nk) {
-      const int64_t k2 = kb + (int64_t)(ks + 2) * kBK;
-      sa.load(a, i0, k2, a_in);
-      sb.load(b, j0, k2, b_in);
-    }
-    float fa[16];
-    read_frag<AMODE, kBM>(s_a[cur], 32 * wave + r, h, fa);
-    float fb[NT][16];
+  int cur = 0;
+  for (; tile < mtiles; tile += gridDim.x) {
+    const int64_t i0 = tile * kBM;
+    // lane-derived offsets (64 output addresses per lane in the epilogue) are invariant across
+    // tiles; hoisted out of this loop they cost ~120 registers and the second wave per SIMD
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int r = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) read_frag<BMODE, BN>(s_b[cur], 32 * n + r, h, fb[n]);
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
-    for (int t = 0; t < 16; ++t)
+      for (int c = 0; c < CH; ++c)
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
-        acc[n][t % CH] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[n][t], acc[n][t % CH], 0, 0, 0);
-    if (bias_grad != nullptr && blockIdx.y == 0 && AMODE == KS) {
-      // A tile is [kk][row]: thread `row` adds its 32 contraction values
-      if (threadIdx.x < kBM) {
-        constexpr int kKsStride = kBM + 4;
+        for (int e = 0; e < 16; ++e) acc[n][c][e] = 0.0f;
+    float colsum = 0.0f;
+    for (int ks = 0; ks < nk; ++ks) {
+      if (t1 < mtiles) {
+        sa.store(s_a[cur ^ 1]);
+        sb.store(s_b[cur ^ 1]);
+      }
+      if (t2 < mtiles) {
+        sa.load(a, t2 * kBM, kb + (int64_t)k2 * kBK, a_in);
+        sb.load(b, j0, kb + (int64_t)k2 * kBK, b_in);
+      }
+      advance(t1, k1);
+      advance(t2, k2);
+      float fa[16];
+      read_frag<AMODE, kBM>(s_a[cur], 32 * wave + r, h, fa);
+      float fb[NT][16];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) read_frag<BMODE, BN>(s_b[cur], 32 * n + r, h, fb[n]);
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[n][t % CH] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[n][t], acc[n][t % CH], 0, 0, 0);
+      if (bias_grad != nullptr && blockIdx.y == 0 && AMODE == KS) {
+        // A tile is [kk][row]: thread `row` adds its 32 contraction values
+        if (threadIdx.x < kBM) {
+          constexpr int kKsStride = kBM + 4;
 #pragma unroll 8
-        for (int kk = 0; kk < kBK; ++kk) colsum += s_a[cur][kk * kKsStride + threadIdx.x];
+          for (int kk = 0; kk < kBK; ++kk) colsum += s_a[cur][kk * kKsStride + threadIdx.x];
+        }
       }
+      __syncthreads();
+      cur ^= 1;
     }
-    __syncthreads();
-  }
 
-  // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    const int64_t j = j0 + 32 * n + r;
-    if (j < N) {
+    for (int n = 0; n < NT; ++n) {
+      const int64_t j = j0 + 32 * n + r;
+      if (j < N) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t i = i0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h;
-        float v = acc[n][0][e];
+        for (int e = 0; e < 16; ++e) {
+          const int64_t i = i0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h;
+          float v = acc[n][0][e];
 #pragma unroll
-        for (int c = 1; c < CH; ++c) v += acc[n][c][e];
-        if (i < M) epi(i, j, v);
+          for (int c = 1; c < CH; ++c) v += acc[n][c][e];
+          if (i < M) epi(i, j, v);
+        }
       }
     }
-  }
-  if (bias_grad != nullptr && blockIdx.y == 0 && AMODE == KS && threadIdx.x < kBM) {
-    const int64_t i = i0 + threadIdx.x;
-    if (i < M) {
-      if (bias_slab_stride)
-        bias_grad[(int64_t)blockIdx.z * bias_slab_stride + i] = colsum;
-      else
-        unsafeAtomicAdd(bias_grad + i, colsum);
+    if (bias_grad != nullptr && blockIdx.y == 0 && AMODE == KS && threadIdx.x < kBM) {
+      const int64_t i = i0 + threadIdx.x;
+      if (i < M) {
+        if (bias_slab_stride)
+          bias_grad[(int64_t)blockIdx.z * bias_slab_stride + i] = colsum;
+        else
+          unsafeAtomicAdd(bias_grad + i, colsum);
+      }
     }
   }
 }
@@ -349,7 +378,13 @@ int launch(const ASrc& a, const BSrc& b, const Epi& e, int64_t M, int N, int64_t
   const int nt = pick_nt(N);
   const int64_t k_chunk = ctr_ceil_div(ctr_ceil_div(K, splits), kBK) * kBK;
   const int zs = (int)ctr_ceil_div(K, k_chunk);
-  const dim3 grid((unsigned)ctr_ceil_div(M, kBM), (unsigned)ctr_ceil_div(N, 32 * nt), (unsigned)zs);
+  // two resident workgroups per CU (LDS), each walking its share of the M tiles
+  const int64_t mtiles = ctr_ceil_div(M, kBM);
+  const int64_t others = ctr_ceil_div(N, 32 * nt) * zs;
+  int64_t gx = ctr_ceil_div(512, others);
+  if (gx > mtiles) gx = mtiles;
+  if (gx < 1) gx = 1;
+  const dim3 grid((unsigned)gx, (unsigned)ctr_ceil_div(N, 32 * nt), (unsigned)zs);
   CTR_REQUIRE(grid.y <= 65535 && grid.z <= 65535, CTR_ELIMIT);
   switch (nt) {
     case 1:

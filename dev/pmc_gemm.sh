@@ -3,7 +3,7 @@
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE"; do
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_$(echo $set | cut -c1-12 | tr ' ' '_') -- python3 $R/dev/gemm_bench.py 65536x256x512 65536x512x96 > /dev/null 2>$R/gpurun_out/pmc.err || tail -3 $R/gpurun_out/pmc.err
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc_$(echo $set | cut -c1-12 | tr ' ' '_') -- python3 $R/dev/gemm_bench.py 3276800x128x128 > /dev/null 2>$R/gpurun_out/pmc.err || tail -3 $R/gpurun_out/pmc.err
 done
 python3 - <<'PY'
 import csv,glob,collections
