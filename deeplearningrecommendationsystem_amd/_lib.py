@@ -15,7 +15,7 @@ import torch  # noqa: F401  (maps libamdhip64 first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTRHIP_LIB", os.path.join(_HERE, "libctrhip.so"))  # env override: A/B builds
-ABI_VERSION = 6
+ABI_VERSION = 7
 DIN_TRIPLE, DIN_PAIR = 0, 1  # layouts of the DIN attention operand (include/ctrhip.h)
 
 CTR_MAX_FIELDS = 32
@@ -71,6 +71,8 @@ SIGNATURES = {
     "ctr_ffm_head_bwd": (_i, [_p, _l, _l, _i, _i, C.POINTER(C.c_int32), _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l,
                               _p, _p, _p, _l, _p, _l, _p, _p, _p, _p, _p, _l, _p, _l, _p]),
     "ctr_act_bwd": (_i, [_p, _l, _p, _l, _p, _l, _l, _i, _i, _i, _p]),
+    "ctr_cross_fwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _p, _l, _l, _i, _p]),
+    "ctr_cross_bwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _p, _l, _p, _l, _i, _p, _l, _p]),
     "ctr_din_concat_fwd": (_i, [_p, _l, _i, _p, _p, _l, _i, _p, _l, _p, _l, _i, _p, _p]),
     "ctr_din_pool_fwd": (_i, [_p, _p, _l, _l, _i, _i, _p, _p, _l, _i, _p]),
     "ctr_din_pool_bwd": (_i, [_p, _p, _l, _l, _i, _i, _p, _l, _i, _p, _p]),

@@ -10,5 +10,6 @@ from .deepcrossing import DeepCrossing
 from .din import DIN
 from .dien import DIEN
 from .embedding_stage import EmbeddingStage
+from .deepcross import DeepCross
 
-__all__ = ["MatrixFactorization", "NeuralCF", "DeepFM", "PNN", "FFM", "DeepCrossing", "DIN", "DIEN", "EmbeddingStage"]
+__all__ = ["MatrixFactorization", "NeuralCF", "DeepFM", "PNN", "FFM", "DeepCrossing", "DIN", "DIEN", "EmbeddingStage", "DeepCross"]

@@ -493,6 +493,29 @@ def act_bwd(y, gy, act: int, out, accumulate: bool) -> None:
     _lib.check(rc, "ctr_act_bwd")
 
 
+def cross_fwd(x0, u, xl, bias, out) -> torch.Tensor:
+    """Deep & Cross combine: out = x0 * u + bias + xl"""
+    x0, u, xl, out = _mat(x0, "x0"), _mat(u, "u"), _mat(xl, "xl"), _mat(out, "out")
+    m, d = x0.shape
+    rc = _timed(f"cross_fwd[{m}x{d}]", lambda: (16 * m * d, 3 * m * d),
+                _lib.load().ctr_cross_fwd, x0.data_ptr(), _ld(x0), u.data_ptr(), _ld(u), xl.data_ptr(), _ld(xl),
+                bias.data_ptr(), out.data_ptr(), _ld(out), m, d, _lib.stream_ptr())
+    _lib.check(rc, "ctr_cross_fwd")
+    return out
+
+
+def cross_bwd(x0, u, gy, gu, gx0, gbias) -> None:
+    """gu = gy * x0; gx0 += gy * u; gbias += gy.sum(0)"""
+    x0, u, gy, gu, gx0 = _mat(x0, "x0"), _mat(u, "u"), _mat(gy, "gy"), _mat(gu, "gu"), _mat(gx0, "gx0")
+    m, d = x0.shape
+    ws = _scratch(x0.device)
+    rc = _timed(f"cross_bwd[{m}x{d}]", lambda: (24 * m * d, 3 * m * d),
+                _lib.load().ctr_cross_bwd, x0.data_ptr(), _ld(x0), u.data_ptr(), _ld(u), gy.data_ptr(), _ld(gy),
+                gu.data_ptr(), _ld(gu), gx0.data_ptr(), _ld(gx0), gbias.data_ptr(), m, d, ws.data_ptr(), ws.numel(),
+                _lib.stream_ptr())
+    _lib.check(rc, "ctr_cross_bwd")
+
+
 # ---------------------------------------------------------------------------
 # DIN / DIEN sequence attention and GRU
 # ---------------------------------------------------------------------------

@@ -193,6 +193,22 @@ int ctr_act_bwd(const float* y, int64_t ldy, const float* gy, int64_t ldgy, floa
                 int64_t m, int n, int act, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Cross layer of Deep & Cross (model/deepcross.py:7-18):
+ *   x_{l+1} = x0 * (W_l x_l) + b_l + x_l,  W_l a bias-free (d, d) nn.Linear.
+ * u = x_l W_l^T is a ctr_linear_fwd call; these are the combine around it.
+ *   fwd: y[m,d] = x0 * u + bias + xl
+ *   bwd: gu = gy * x0 (operand of the layer's dX / dW, i.e. ctr_linear_bwd with gy := gu),
+ *        gx0 += gy * u, gbias += column sums of gy (through `workspace`, fixed order).
+ *        The gradient w.r.t. x_l is gy + gu W_l: accumulate the dX of ctr_linear_bwd
+ *        (accumulate_gx) into the gy buffer.   d <= 1024.
+ * ---------------------------------------------------------------------- */
+int ctr_cross_fwd(const float* x0, int64_t ldx0, const float* u, int64_t ldu, const float* xl, int64_t ldxl,
+                  const float* bias, float* y, int64_t ldy, int64_t m, int d, void* stream);
+int ctr_cross_bwd(const float* x0, int64_t ldx0, const float* u, int64_t ldu, const float* gy, int64_t ldgy,
+                  float* gu, int64_t ldgu, float* gx0, int64_t ldgx0, float* gbias, int64_t m, int d,
+                  float* workspace, int64_t workspace_floats, void* stream);
+
+/* ------------------------------------------------------------------------
  * DIN / DIEN attention over the behaviour sequence (model/din.py:33-53,
  * model/dien.py:23-39).  hist is (batch, len) int64 row-major, target (batch,).
  * ---------------------------------------------------------------------- */

@@ -209,6 +209,55 @@ def deepcrossing_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
     return torch.sigmoid(_lin(p, "linear", r))
 
 
+def stack_5e1(p: Params, x: torch.Tensor) -> torch.Tensor:
+    """cat[user, item, age(1), gender, occupation, movie] -> (B, 5E+1): the stack shared by
+    model/deepcrossing.py:63-71, model/deepcross.py:61-70 and model/widedeep.py:44-52"""
+    return torch.cat([
+        _emb(p, "user_embedding", ids_from_float(x[:, COL_USER])),
+        _emb(p, "item_embedding", ids_from_float(x[:, COL_ITEM])),
+        x[:, COL_AGE].unsqueeze(1),
+        bag_pool(x[:, SL_GENDER], p["gender_embedding.weight"]),
+        bag_pool(x[:, SL_OCC], p["occupation_embedding.weight"]),
+        bag_pool(x[:, SL_GENRE], p["movie_embedding.weight"]),
+    ], dim=1)
+
+
+def deepcross_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
+    """model/deepcross.py:59-77 (Deep & Cross): CrossNetwork :7-18
+    ``x_{l+1} = x0 * (W_l x_l) + b_l + x_l`` (W_l a bias-free d x d Linear), DeepNetwork
+    :21-31 (Linear+ReLU after EVERY layer), output Linear(d + H_last, 1) + sigmoid -> (B,1)"""
+    x0 = stack_5e1(p, x)
+    xl = x0
+    n = 0
+    while f"cross_network.cross_weights.{n}.weight" in p:
+        xl = x0 * (xl @ p[f"cross_network.cross_weights.{n}.weight"].T) + p[f"cross_network.cross_biases.{n}"] + xl
+        n += 1
+    h = x0
+    k = 0
+    while f"deep_network.network.{2 * k}.weight" in p:
+        h = torch.relu(_lin(p, f"deep_network.network.{2 * k}", h))
+        k += 1
+    return torch.sigmoid(_lin(p, "output_layer", torch.cat([xl, h], dim=1)))
+
+
+def widedeep_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
+    """model/widedeep.py:41-66: deep = Linear(5E+1, H0) WITHOUT activation (:55) then
+    Linear+ReLU per pair (:56-58); wide = user(u) + item(i) + Linear(43,1)(x[:,2:]) (:61);
+    sigmoid(Linear(2,1)(cat(wide, deep))) -> (B,1)"""
+    deep = _lin(p, "linear", stack_5e1(p, x))
+    for k in range(_count(p, "dnn_network")):
+        deep = torch.relu(_lin(p, f"dnn_network.{k}", deep))
+    uid, iid = ids_from_float(x[:, COL_USER]), ids_from_float(x[:, COL_ITEM])
+    wide = _emb(p, "user", uid) + _emb(p, "item", iid) + _lin(p, "wide", x[:, 2:])
+    return torch.sigmoid(_lin(p, "output", torch.cat([wide, deep], dim=1)))
+
+
+def lr_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
+    """model/lr.py:24-25: sigmoid(user(u) + item(i) + Linear(43,1)(x[:,2:])) -> (B,1)"""
+    uid, iid = ids_from_float(x[:, COL_USER]), ids_from_float(x[:, COL_ITEM])
+    return torch.sigmoid(_emb(p, "user", uid) + _emb(p, "item", iid) + _lin(p, "linear", x[:, 2:]))
+
+
 def _count_res(p: Params) -> int:
     n = 0
     while f"res_layers.{n}.linear1.weight" in p:
@@ -301,7 +350,7 @@ def bce_loss(prob: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
 FORWARDS: Dict[str, Callable[..., torch.Tensor]] = {
     "mf": mf_forward, "neuralcf": neuralcf_forward, "ffm": ffm_forward, "pnn": pnn_forward,
     "deepcrossing": deepcrossing_forward, "deepfm": deepfm_forward, "din": din_forward,
-    "dien": dien_forward,
+    "dien": dien_forward, "deepcross": deepcross_forward, "widedeep": widedeep_forward, "lr": lr_forward,
 }
 
 

@@ -38,8 +38,12 @@ def _ref_classes():
     from model.deepfm import DeepFM
     from model.din import DIN
     from model.dien import DIEN
+    from model.deepcross import DeepCross
+    from model.widedeep import WideDeep
+    from model.lr import LogisticRegression
     return dict(mf=MatrixFactorization, neuralcf=NeuralCF, ffm=FFM, pnn=PNN,
-                deepcrossing=DeepCrossing, deepfm=DeepFM, din=DIN, dien=DIEN)
+                deepcrossing=DeepCrossing, deepfm=DeepFM, din=DIN, dien=DIEN,
+                deepcross=DeepCross, widedeep=WideDeep, lr=LogisticRegression)
 
 
 # name -> (model key, ctor args, ctor kwargs, input builder(gen) -> (inputs, y))
@@ -87,6 +91,14 @@ def _cases():
     c["din_allpad"] = ("din", (20, 8), {}, seq(16, 6, 20, pad=1.0), 4)
     c["dien_l1"] = ("dien", (20, 4), {}, seq(37, 1, 20), 2)
     c["dien_l33"] = ("dien", (20, 4), {}, seq(9, 33, 20), 3)
+    # models built from the same primitives (DCN cross layers, Wide&Deep, LR)
+    for s in (0, 1):
+        c[f"deepcross_s{s}"] = ("deepcross", (30, 40, 3, [32, 16, 1], 8), {}, feats(64, 30, 40, 4), s)
+        c[f"widedeep_s{s}"] = ("widedeep", (30, 40, [32, 16, 1], 8), {}, feats(64, 30, 40, 4), s)
+        c[f"lr_s{s}"] = ("lr", (30, 40, 43), {}, feats(64, 30, 40, 4), s)
+    c["deepcross_b37"] = ("deepcross", (5, 7, 2, [16, 8], 4), {}, feats(37, 5, 7), 2)
+    c["widedeep_b37"] = ("widedeep", (5, 7, [16, 1], 4), {}, feats(37, 5, 7), 2)
+    c["lr_b37"] = ("lr", (5, 7, 43), {}, feats(37, 5, 7), 2)
     return c
 
 

@@ -23,7 +23,8 @@ def _models():
     from deeplearningrecommendationsystem_amd import model
     return {name: getattr(model, cls) for name, cls in
             dict(mf="MatrixFactorization", neuralcf="NeuralCF", ffm="FFM", pnn="PNN",
-                 deepcrossing="DeepCrossing", deepfm="DeepFM", din="DIN", dien="DIEN").items()
+                 deepcrossing="DeepCrossing", deepfm="DeepFM", din="DIN", dien="DIEN", deepcross="DeepCross",
+                 widedeep="WideDeep", lr="LogisticRegression").items()
             if hasattr(model, cls)}
 
 

@@ -388,6 +388,31 @@ def test_din_pair_operand_and_folded_first_layer(ops, dim, length, batch):
     torch.testing.assert_close(gw.cpu(), wl.grad.float(), rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("m,d", [(1000, 41), (257, 64), (3, 5), (4096, 641)])
+def test_cross_layer_combine(ops, m, d):
+    # model/deepcross.py:14-17: x_{l+1} = x0 * u + b + x_l and its backward pieces
+    g = torch.Generator().manual_seed(m + d)
+    x0, u, xl, gy = (torch.randn(m, d, generator=g) for _ in range(4))
+    b = torch.randn(d, generator=g)
+    pad = (d + 3) // 4 * 4
+    dev = lambda t: torch.zeros(m, pad, device=DEV)[:, :d].copy_(t)  # noqa: E731  (16-byte aligned rows)
+    out = torch.empty(m, pad, device=DEV)[:, :d]
+    ops.cross_fwd(dev(x0), dev(u), dev(xl), b.to(DEV), out)
+    torch.testing.assert_close(out.cpu(), x0 * u + b + xl, rtol=1e-6, atol=1e-6)
+    # unaligned operands take the scalar path
+    out2 = torch.empty(m, d, device=DEV)
+    ops.cross_fwd(x0.to(DEV), u.to(DEV), xl.to(DEV), b.to(DEV), out2)
+    torch.testing.assert_close(out2.cpu(), x0 * u + b + xl, rtol=1e-6, atol=1e-6)
+    gu = torch.empty(m, d, device=DEV)
+    gx0_start = torch.randn(m, d, generator=g)
+    gx0 = gx0_start.to(DEV)
+    gb = torch.zeros(d, device=DEV)
+    ops.cross_bwd(x0.to(DEV), u.to(DEV), gy.to(DEV), gu, gx0, gb)
+    torch.testing.assert_close(gu.cpu(), gy * x0, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(gx0.cpu(), gx0_start + gy * u, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(gb.cpu(), gy.double().sum(0).float(), rtol=1e-5, atol=1e-5 * m ** 0.5)
+
+
 def test_embed_backward_padding_row_and_large_table(ops):
     # a 100k-row table (atomic scatter path) where 30 % of the ids are 0, the padding id of the
     # behaviour sequences: row 0 is pre-reduced per workgroup instead of 20k same-address atomics
