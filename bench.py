@@ -45,6 +45,10 @@ WORKLOADS = {
     "deepcrossing": "deepcrossing emb=32 hidden=[256,128,64,32] ml-100k vocab batch=65536/gpu",
     "din": "din items=1e7 emb=64 L=100 batch=32768/gpu (BASELINE configs[4], single GPU)",
     "dien": "dien items=1e7 emb=16 L=100 batch=32768/gpu (BASELINE configs[4], single GPU)",
+    # further zoo models built from the same kernels (script shapes)
+    "deepcross": "deepcross (DCN) 3 cross layers, deep=[512,256,128,1] emb=128 (d=641) ml-100k vocab batch=65536/gpu",
+    "widedeep": "widedeep hidden=[512,256,128,1] emb=128 ml-100k vocab batch=65536/gpu",
+    "lr": "lr 43 features ml-100k vocab batch=65536/gpu",
     # the embedding stage alone at the roofline shape of SURVEY.md 8(d) cfg3b (metric ii: gather GB/s)
     "gather26": "embedding stage 26 fields x 1e6 rows x emb=16 batch=65536/gpu, uniform ids (gather fwd + dense-grad scatter bwd)",
     "gather26zipf": "embedding stage 26 fields x 1e6 rows x emb=16 batch=65536/gpu, Zipf(1.05) ids",
@@ -59,7 +63,7 @@ def make_inputs(name: str, rank: int, batch: int):
         return [u, i], synth.labels(batch, name != "mf", gen)
     if name in ("deepfm",):
         return [synth.feature_batch(batch, 1_000_000, 1_000_000, gen)], synth.labels(batch, True, gen)
-    if name in ("pnn", "ffm", "deepcrossing"):
+    if name in ("pnn", "ffm", "deepcrossing", "deepcross", "widedeep", "lr"):
         return [synth.feature_batch(batch, gen=gen)], synth.labels(batch, True, gen)
     if name in ("din", "dien"):
         hist, target = synth.hist_batch(batch, 100, 10_000_000, gen)
@@ -101,6 +105,12 @@ def make_model(name: str, shard: bool = False):
         return zoo.DIN(10_000_000, 64)
     if name == "dien":
         return zoo.DIEN(10_000_000, 16)
+    if name == "deepcross":
+        return zoo.DeepCross(943, 1682, 3, [512, 256, 128, 1], 128)   # scripts/deepcross.py:52-53
+    if name == "widedeep":
+        return zoo.WideDeep(943, 1682, [512, 256, 128, 1], 128)       # scripts/widedeep.py
+    if name == "lr":
+        return zoo.LogisticRegression(943, 1682, 43)                  # scripts/lr.py
     if name in ("gather26", "gather26zipf"):
         return zoo.EmbeddingStage(26, 1_000_000, 16)
     raise SystemExit(f"unknown workload {name}")
@@ -346,7 +356,7 @@ def main():
                 "ms_per_step": full_ms, "samples_per_s": batch_of(args.workload) / full_ms * 1e3,
                 "what": "zero_grad + forward + BCELoss + backward + Adam(lr=1e-3, weight_decay=1e-5).step()"},
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload in ("neuralcf", "mf", "pnn", "ffm", "deepcrossing"):
+        if world == 1 and not args.no_cpu_baseline and args.workload in ("neuralcf", "mf", "pnn", "ffm", "deepcrossing", "deepcross", "widedeep", "lr"):
             out["cpu_baseline"] = cpu_baseline(args.workload, model)
         print(json.dumps(out))
     if dist.is_initialized():

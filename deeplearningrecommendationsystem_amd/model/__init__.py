@@ -11,5 +11,7 @@ from .din import DIN
 from .dien import DIEN
 from .embedding_stage import EmbeddingStage
 from .deepcross import DeepCross
+from .widedeep import WideDeep
+from .lr import LogisticRegression
 
-__all__ = ["MatrixFactorization", "NeuralCF", "DeepFM", "PNN", "FFM", "DeepCrossing", "DIN", "DIEN", "EmbeddingStage", "DeepCross"]
+__all__ = ["MatrixFactorization", "NeuralCF", "DeepFM", "PNN", "FFM", "DeepCrossing", "DIN", "DIEN", "EmbeddingStage", "DeepCross", "WideDeep", "LogisticRegression"]
