@@ -34,8 +34,11 @@ bag_bwd_kernel(const Bags B, int first, int64_t ldx, uint32_t batch, const float
                float* __restrict__ ws, int64_t slab) {
   __shared__ float s_part[(kBlock / 64) * KMAX * 64];
   const Bag bag = B.b[first + blockIdx.y];
+  if ((int)blockIdx.z * 64 >= bag.width && blockIdx.z > 0) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int e = bag.width, spw = 64 / e;  // samples per wave and step
+  // rows wider than a wave are cut into 64-column chunks (blockIdx.z)
+  const int e = bag.width < 64 ? bag.width : 64, spw = 64 / e;  // columns / samples per wave and step
+  const int cbase = blockIdx.z * 64;
   const int col = lane & (e - 1), sub = lane / e;
   float acc[KMAX];
 #pragma unroll
@@ -45,8 +48,8 @@ bag_bwd_kernel(const Bags B, int first, int64_t ldx, uint32_t batch, const float
     // two samples per lane in flight
     const uint32_t s0 = b0 + sub, s1 = b0 + step + sub;
     const bool ok0 = s0 < batch, ok1 = s1 < batch;
-    const float g0 = ok0 ? ctr_ldg(gout + (int64_t)s0 * ldo + bag.out_col + col) : 0.0f;
-    const float g1 = ok1 ? ctr_ldg(gout + (int64_t)s1 * ldo + bag.out_col + col) : 0.0f;
+    const float g0 = ok0 ? ctr_ldg(gout + (int64_t)s0 * ldo + bag.out_col + cbase + col) : 0.0f;
+    const float g1 = ok1 ? ctr_ldg(gout + (int64_t)s1 * ldo + bag.out_col + cbase + col) : 0.0f;
     const float* x0 = bag.xcol + (int64_t)(ok0 ? s0 : 0) * ldx;
     const float* x1 = bag.xcol + (int64_t)(ok1 ? s1 : 0) * ldx;
     float w0[KMAX], w1[KMAX];
@@ -73,13 +76,13 @@ bag_bwd_kernel(const Bags B, int first, int64_t ldx, uint32_t batch, const float
     float t = 0.0f;
 #pragma unroll
     for (int w = 0; w < kBlock / 64; ++w) t += s_part[(w * KMAX + j) * 64 + c];
-    out[i] = t;
+    out[j * bag.width + cbase + c] = t;
   }
 }
 
 }  // namespace
 
-// Takes every bag field with a power-of-two width <= 64 and <= 32 rows; handled[i] = 1 for
+// Takes every bag field with a power-of-two width <= 1024 and <= 32 rows; handled[i] = 1 for
 // those.  Uses the first *used_floats of the workspace.
 int ctr_embed_bwd_bags(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch,
                        const float* gout, int64_t ldo, float* workspace, int64_t workspace_floats,
@@ -94,7 +97,7 @@ int ctr_embed_bwd_bags(const ctr_field_t* fields, int nfields, const float* x, i
     const ctr_field_t& f = fields[i];
     if (f.kind != CTR_FIELD_BAG || !f.grad || handled[i]) continue;
     const bool pow2 = f.width > 0 && (f.width & (f.width - 1)) == 0;
-    if (!pow2 || f.width > 64 || f.bag_size > 32) continue;
+    if (!pow2 || f.width > 1024 || f.bag_size > 32) continue;
     B.b[B.n] = Bag{x + f.src_col, f.out_col, f.width, f.bag_size, (int)slab};
     idx_of[B.n++] = i;
     slab += (int64_t)f.bag_size * f.width;
@@ -120,7 +123,9 @@ int ctr_embed_bwd_bags(const ctr_field_t* fields, int nfields, const float* x, i
   for (int c = 0; c < 3; ++c) {
     const int cnt = start[c + 1] - start[c];
     if (cnt == 0) continue;
-    const dim3 grid(nblk, cnt);
+    int zmax = 1;
+    for (int k = start[c]; k < start[c + 1]; ++k) zmax = (sorted.b[k].width + 63) / 64 > zmax ? (sorted.b[k].width + 63) / 64 : zmax;
+    const dim3 grid(nblk, cnt, zmax);
     if (c == 0)
       hipLaunchKernelGGL(bag_bwd_kernel<2>, grid, dim3(kBlock), 0, st, sorted, start[c], ldx, (uint32_t)batch, gout, ldo,
                          workspace, slab);

@@ -38,7 +38,7 @@ def _feature_specs(ops, tabs, widths_e, ldo_cols=True):
     ]
 
 
-@pytest.mark.parametrize("e,batch", [(16, 1000), (8, 37), (4, 1), (64, 4096), (6, 129), (1, 77)])
+@pytest.mark.parametrize("e,batch", [(16, 1000), (8, 37), (4, 1), (64, 4096), (6, 129), (1, 77), (128, 2048), (256, 300)])
 def test_embed_stage_forward_and_backward(ops, e, batch):
     from deeplearningrecommendationsystem_amd import synth
     g = synth.generator(e * 1000 + batch)
