@@ -28,7 +28,7 @@ struct SortJob {
   int32_t vocab;
   int32_t* hist;        // [nblk][vocab] per-workgroup histograms
   int32_t* base;        // [nblk][vocab] samples of the row in earlier workgroups
-  int32_t* total;       // [vocab] samples of the row, then (scanned) its first sorted position
+  int32_t* total;       // [vocab] samples of the row
   int32_t* order;       // [batch] sample of every sorted position
   int32_t* keys;        // [batch] row of every sorted position
 };
@@ -61,8 +61,8 @@ __device__ __forceinline__ int load_row(const SortJob& j, uint32_t b) {
 // [w*chunk, (w+1)*chunk) of the batch in both passes:
 //   count:   LDS histogram of the slice -> hist[w][:]            (plain stores, no memset)
 //   colscan: base[w][v] = sum_{w'<w} hist[w'][v],  total[v] = sum_w hist[w][v]
-//   rowscan: total[v]  <- sum_{v'<v} total[v']
-//   scatter: LDS cursors start at total[:] + base[w][:], ds_add_rtn hands out the positions
+//   scatter: LDS cursors start at (exclusive scan of total)[:] + base[w][:], ds_add_rtn hands
+//            out the positions
 __global__ void __launch_bounds__(kBlock) sort_count_kernel(const SortJobs J, uint32_t batch, uint32_t chunk) {
   extern __shared__ int s_hist[];
   const SortJob j = J.j[blockIdx.y];
@@ -96,40 +96,35 @@ __global__ void __launch_bounds__(kBlock) sort_colscan_kernel(const SortJobs J, 
   j.total[v] = run;
 }
 
-// exclusive scan of the <= kMaxVocab row totals, one workgroup of 1024 per job
-__global__ void __launch_bounds__(1024) sort_rowscan_kernel(const SortJobs J) {
-  __shared__ int s_part[1024];
-  const SortJob j = J.j[blockIdx.x];
-  constexpr int kPer = kMaxVocab / 1024;
-  int v[kPer], sum = 0;
-#pragma unroll
-  for (int i = 0; i < kPer; ++i) {
-    const int at = threadIdx.x * kPer + i;
-    v[i] = at < j.vocab ? j.total[at] : 0;
-    sum += v[i];
+// every workgroup scans the row totals itself (<= 32 per thread + one 256-wide block scan:
+// cheaper than a separate single-workgroup launch), then hands out positions from LDS cursors
+__global__ void __launch_bounds__(kBlock) sort_scatter_kernel(const SortJobs J, uint32_t batch, uint32_t chunk) {
+  extern __shared__ int s_cur[];
+  __shared__ int s_part[kBlock];
+  const SortJob j = J.j[blockIdx.y];
+  const int per = (j.vocab + kBlock - 1) / kBlock;  // consecutive rows owned by a thread
+  const int v0 = threadIdx.x * per;
+  int sum = 0;
+  for (int i = 0; i < per; ++i) {
+    const int v = v0 + i;
+    const int t = v < j.vocab ? j.total[v] : 0;
+    if (v < j.vocab) s_cur[v] = sum;  // exclusive prefix inside the thread's run
+    sum += t;
   }
   s_part[threadIdx.x] = sum;
   __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
+  for (int d = 1; d < kBlock; d <<= 1) {
     const int t = threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
     __syncthreads();
     s_part[threadIdx.x] += t;
     __syncthreads();
   }
-  int run = s_part[threadIdx.x] - sum;
-#pragma unroll
-  for (int i = 0; i < kPer; ++i) {
-    const int at = threadIdx.x * kPer + i;
-    if (at < j.vocab) j.total[at] = run;
-    run += v[i];
-  }
-}
-
-__global__ void __launch_bounds__(kBlock) sort_scatter_kernel(const SortJobs J, uint32_t batch, uint32_t chunk) {
-  extern __shared__ int s_cur[];
-  const SortJob j = J.j[blockIdx.y];
+  const int before = s_part[threadIdx.x] - sum;
   const int32_t* mine = j.base + (int64_t)blockIdx.x * j.vocab;
-  for (int v = threadIdx.x; v < j.vocab; v += kBlock) s_cur[v] = mine[v] + j.total[v];
+  for (int i = 0; i < per; ++i) {
+    const int v = v0 + i;
+    if (v < j.vocab) s_cur[v] += before + mine[v];
+  }
   __syncthreads();
   const uint32_t lo = blockIdx.x * chunk, hi = lo + chunk < batch ? lo + chunk : batch;
   for (uint32_t b = lo + threadIdx.x; b < hi; b += kBlock) {
@@ -371,7 +366,6 @@ int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x,
   hipLaunchKernelGGL(sort_count_kernel, dim3(nblk, J.n), dim3(kBlock), sizeof(int) * maxv, st, J, (uint32_t)batch,
                      (uint32_t)chunk);
   hipLaunchKernelGGL(sort_colscan_kernel, dim3((unsigned)ctr_ceil_div(maxv, kBlock), J.n), dim3(kBlock), 0, st, J, nblk);
-  hipLaunchKernelGGL(sort_rowscan_kernel, dim3(J.n), dim3(1024), 0, st, J);
   hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblk, J.n), dim3(kBlock), sizeof(int) * maxv, st, J, (uint32_t)batch,
                      (uint32_t)chunk);
   // grid.x sized for the narrowest stream's groups-per-workgroup; wider streams exit early

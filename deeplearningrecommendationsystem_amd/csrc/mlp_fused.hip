@@ -175,11 +175,24 @@ __device__ __forceinline__ void stage_weights(float* s_w, const StackDesc& d, bo
     // rows [n, round_up(n, 8)) are staged as zeros: the contraction chunks of dX run over
     // multiples of 8 and need no per-element range check
     const int units = (L.n + 7) / 8 * 8 * (L.k / 4);  // k % 4 == 0: a float4 never crosses a row
-    for (int u = threadIdx.x; u < units; u += blockDim.x) {
-      const int r = (int)ctr_div((uint32_t)u, L.div_k4), c = (u - r * (L.k / 4)) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < L.n) v = *reinterpret_cast<const float4*>(L.w + (int64_t)r * L.k + c);
-      *reinterpret_cast<float4*>(dst + r * ws + c) = v;
+    // four loads in flight per thread: a load-store loop pays one L2 round trip per iteration
+    for (int u0 = threadIdx.x; u0 < units; u0 += 4 * blockDim.x) {
+      float4 v[4];
+      int off[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int u = u0 + q * blockDim.x;
+        v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        off[q] = -1;
+        if (u < units) {
+          const int r = (int)ctr_div((uint32_t)u, L.div_k4), c = (u - r * (L.k / 4)) * 4;
+          off[q] = r * ws + c;
+          if (r < L.n) v[q] = *reinterpret_cast<const float4*>(L.w + (int64_t)r * L.k + c);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (off[q] >= 0) *reinterpret_cast<float4*>(dst + off[q]) = v[q];
     }
   }
 }
