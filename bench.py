@@ -175,6 +175,15 @@ KERNEL_NAMES = {"mlp_fused_bwd": "mlp_bwd_kernel", "mlp_fused_fwd": "mlp_fwd_ker
                 "embed_bwd": "embed_bwd_kernel", "mf_fwd": "mf_fwd_kernel", "mf_bwd": "mf_bwd_kernel"}
 
 
+# what one event-bracketed C-ABI call covers when it is more than one kernel
+LABEL_NOTES = {
+    "mlp_fused_bwd": "one ctr_mlp_bwd call = mlp_bwd_kernel + reduce_segments_kernel (+ the gap between them); "
+                     "rocprofv3 lists them separately in profiles/*_kernel_stats.csv",
+    "embed_bwd": "one ctr_embed_bwd call = sort_count/colscan/scatter + seg_reduce (small tables) and/or "
+                 "bag_bwd + reduce_segments and/or embed_bwd_kernel",
+}
+
+
 def pmc_traffic(workload, label):
     """HBM bytes per launch of `label` from the newest committed PMC pass (dev/pmc_traffic.sh, FETCH_SIZE and
     WRITE_SIZE collected in separate rocprofv3 passes).  FETCH_SIZE is doubled for the gfx950 wide-read
@@ -319,7 +328,7 @@ def main():
         full_ms = (time.perf_counter() - t1) / nfull * 1e3
 
     # per-kernel durations: the same steps again with a HIP event pair around every launch
-    prof = ops.KernelProfiler()
+    prof = ops.KernelProfiler(spacer_us=60.0)  # GPU kept busy ahead of each bracketed launch: no host gap in the pair
     ops.set_profiler(prof)
     for _ in range(args.steps):
         eager_step()
@@ -345,7 +354,8 @@ def main():
                        "parallelism": (f"dp{world}+rowshard{world}" if args.shard else f"dp{world}") if world > 1 or args.shard
                        else "single"},
             "loss": float(loss.item()), "launch": "eager" if args.no_graph else "hipGraph replay",
-            "roofline": dict(entries[dominant], traffic=pmc_traffic(args.workload, dominant)),
+            "roofline": dict(entries[dominant], traffic=pmc_traffic(args.workload, dominant),
+                             note=LABEL_NOTES.get(dominant)),
             "gather_roofline": None if "embed_fwd" not in entries else
             dict(entries["embed_fwd"], traffic=pmc_traffic(args.workload, "embed_fwd")),
             "kernels": {k: {"avg_us": round(v["avg_us"], 2), "calls_per_step": v["calls"] / args.steps,
