@@ -24,8 +24,10 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int kThreads = 256;
 constexpr int kBM = 128;
-constexpr int kBK = 32;
-constexpr int kKcStride = kBK + 4;  // floats; 144 B rows: conflict-free b128 reads (guide G4)
+constexpr int kBK = 16;             // contraction depth of one pipeline step
+constexpr int kHalf = kBK / 2;      // values per lane and step: the lane halves take kk = kHalf*h + t
+constexpr int kKcStride = kBK + 4;  // floats; 80 B rows: 8 consecutive rows cover all 32 banks with b128 reads
+constexpr int kWgPerCu = 3;         // 41 KB of LDS and <= 170 VGPRs per workgroup: three resident per CU
 
 enum { KC = 0, KS = 1 };
 
@@ -147,7 +149,9 @@ struct AtomicEpi {
 // column of the tile, `k0` the first contraction index.
 template <int MODE, int ROWS, class Src>
 struct Stager {
-  static constexpr int kVecs = ROWS * kBK / 4 / kThreads;  // float4 per thread
+  static constexpr int kUnits = ROWS * kBK / 4;                           // float4 in the tile
+  static constexpr int kVecs = (kUnits + kThreads - 1) / kThreads;        // float4 per thread
+  static constexpr bool kPartial = kUnits % kThreads != 0;                // narrow tiles: some threads idle
   static constexpr int kKsStride = ROWS + 4;
   static constexpr int kLdsFloats = MODE == KC ? ROWS * kKcStride : kBK * kKsStride;
   float4 reg[kVecs];
@@ -158,8 +162,10 @@ struct Stager {
     if (fast) {
 #pragma unroll
       for (int p = 0; p < kVecs; ++p) {
-        if (MODE == KC) {
-          const int c4 = t & 7, r = (t >> 3) + 32 * p;
+        if (kPartial && t + kThreads * p >= kUnits) {
+          reg[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (MODE == KC) {
+          const int c4 = t % (kBK / 4), r = t / (kBK / 4) + (kThreads / (kBK / 4)) * p;
           reg[p] = s.load4_fast(row0 + r, k0 + c4 * 4);
         } else {
           constexpr int kPerRow = ROWS / 4;  // float4 per kk row
@@ -172,8 +178,10 @@ struct Stager {
     }
 #pragma unroll
     for (int p = 0; p < kVecs; ++p) {
-      if (MODE == KC) {
-        const int c4 = t & 7, r = (t >> 3) + 32 * p;
+      if (kPartial && t + kThreads * p >= kUnits) {
+        reg[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else if (MODE == KC) {
+        const int c4 = t % (kBK / 4), r = t / (kBK / 4) + (kThreads / (kBK / 4)) * p;
         reg[p] = s.load4(row0 + r, k0 + c4 * 4);
       } else {
         constexpr int kPerRow = ROWS / 4;
@@ -187,8 +195,10 @@ struct Stager {
     const int t = threadIdx.x;
 #pragma unroll
     for (int p = 0; p < kVecs; ++p) {
-      if (MODE == KC) {
-        const int c4 = t & 7, r = (t >> 3) + 32 * p;
+      if (kPartial && t + kThreads * p >= kUnits) {
+        // idle thread of a narrow tile
+      } else if (MODE == KC) {
+        const int c4 = t % (kBK / 4), r = t / (kBK / 4) + (kThreads / (kBK / 4)) * p;
         *reinterpret_cast<float4*>(lds + r * kKcStride + c4 * 4) = reg[p];
       } else {
         constexpr int kPerRow = ROWS / 4;
@@ -200,25 +210,25 @@ struct Stager {
   }
 };
 
-// the 16 contraction values (kk = 16h .. 16h+15) of tile row `r` for this lane
+// the kHalf contraction values (kk = kHalf*h .. kHalf*h + kHalf-1) of tile row `r` for this lane
 template <int MODE, int ROWS>
-__device__ __forceinline__ void read_frag(const float* lds, int r, int h, float (&f)[16]) {
+__device__ __forceinline__ void read_frag(const float* lds, int r, int h, float (&f)[kHalf]) {
   if (MODE == KC) {
-    const float4* q = reinterpret_cast<const float4*>(lds + r * kKcStride + 16 * h);
+    const float4* q = reinterpret_cast<const float4*>(lds + r * kKcStride + kHalf * h);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < kHalf / 4; ++v) {
       const float4 x = q[v];
       f[4 * v + 0] = x.x; f[4 * v + 1] = x.y; f[4 * v + 2] = x.z; f[4 * v + 3] = x.w;
     }
   } else {
     constexpr int kKsStride = ROWS + 4;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) f[t] = lds[(16 * h + t) * kKsStride + r];
+    for (int t = 0; t < kHalf; ++t) f[t] = lds[(kHalf * h + t) * kKsStride + r];
   }
 }
 
 template <int NT, int AMODE, int BMODE, class ASrc, class BSrc, class Epi>
-__global__ void __launch_bounds__(kThreads, 2)  /* two waves per SIMD: the 2 workgroups per CU the LDS allows */
+__global__ void __launch_bounds__(kThreads, kWgPerCu)  /* waves per SIMD = resident workgroups per CU (LDS) */
 gemm_tile_kernel(const ASrc a, const BSrc b, const Epi epi, int64_t M, int N, int64_t K, int64_t k_chunk,
                  float* __restrict__ bias_grad /* dW pass only: column sums of A */,
                  int64_t bias_slab_stride /* 0: atomics into bias_grad, else slab z of it */) {
@@ -305,13 +315,13 @@ gemm_tile_kernel(const ASrc a, const BSrc b, const Epi epi, int64_t M, int N, in
       }
       advance(t1, k1);
       advance(t2, k2);
-      float fa[16];
+      float fa[kHalf];
       read_frag<AMODE, kBM>(s_a[cur], 32 * wave + r, h, fa);
-      float fb[NT][16];
+      float fb[NT][kHalf];
 #pragma unroll
       for (int n = 0; n < NT; ++n) read_frag<BMODE, BN>(s_b[cur], 32 * n + r, h, fb[n]);
 #pragma unroll
-      for (int t = 0; t < 16; ++t)
+      for (int t = 0; t < kHalf; ++t)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
           acc[n][t % CH] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[n][t], acc[n][t % CH], 0, 0, 0);
@@ -378,10 +388,10 @@ int launch(const ASrc& a, const BSrc& b, const Epi& e, int64_t M, int N, int64_t
   const int nt = pick_nt(N);
   const int64_t k_chunk = ctr_ceil_div(ctr_ceil_div(K, splits), kBK) * kBK;
   const int zs = (int)ctr_ceil_div(K, k_chunk);
-  // two resident workgroups per CU (LDS), each walking its share of the M tiles
+  // kWgPerCu resident workgroups per CU (LDS), each walking its share of the M tiles
   const int64_t mtiles = ctr_ceil_div(M, kBM);
   const int64_t others = ctr_ceil_div(N, 32 * nt) * zs;
-  int64_t gx = ctr_ceil_div(512, others);
+  int64_t gx = ctr_ceil_div(256 * kWgPerCu, others);
   if (gx > mtiles) gx = mtiles;
   if (gx < 1) gx = 1;
   const dim3 grid((unsigned)gx, (unsigned)ctr_ceil_div(N, 32 * nt), (unsigned)zs);
@@ -454,7 +464,7 @@ extern "C" int ctr_linear_bwd(const float* x, int64_t ldx, const float* w, int64
     // and only occupancy hides their HBM latency (256 chunks = 1 workgroup per CU ran 4x slower)
     const int64_t target = tiles >= 4 ? 1024 : 1536;
     int64_t splits = (target + tiles - 1) / tiles;
-    const int64_t max_splits = ctr_ceil_div(m, 4 * kBK);   // at least 128 rows each
+    const int64_t max_splits = ctr_ceil_div(m, 128);   // at least 128 rows each
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     CTR_REQUIRE(gw != nullptr, CTR_EINVAL);  // gb without gw is not used by any model

@@ -185,7 +185,7 @@ def test_linear_forward(ops, m, n, k, act):
     y = ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), act).cpu()
     ref = x.double() @ w.double().T + b.double()
     ref = [ref, torch.relu(ref), torch.sigmoid(ref)][act]
-    torch.testing.assert_close(y, ref.float(), rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(y, ref.float(), rtol=1e-5, atol=4e-6)  # fp32 sum over k terms in tile order: a few ulp of the largest partial sum
 
 
 @pytest.mark.parametrize("m,n,k", LINEAR_SHAPES)
