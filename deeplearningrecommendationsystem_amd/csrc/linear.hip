@@ -27,7 +27,9 @@ constexpr int kBM = 128;
 constexpr int kBK = 16;             // contraction depth of one pipeline step
 constexpr int kHalf = kBK / 2;      // values per lane and step: the lane halves take kk = kHalf*h + t
 constexpr int kKcStride = kBK + 4;  // floats; 80 B rows: 8 consecutive rows cover all 32 banks with b128 reads
-constexpr int kWgPerCu = 3;         // 41 KB of LDS and <= 170 VGPRs per workgroup: three resident per CU
+// resident workgroups per CU = waves per SIMD.  Forward (both operands KC): 41 KB of LDS -> 3;
+// dX / dW stage one or both operands [kk][row] (34-37 KB) and fit 4 with <= 128 VGPRs
+constexpr int wg_per_cu(int amode, int bmode) { return (amode == 0 && bmode == 0) ? 3 : 4; }
 
 enum { KC = 0, KS = 1 };
 
@@ -228,7 +230,7 @@ __device__ __forceinline__ void read_frag(const float* lds, int r, int h, float 
 }
 
 template <int NT, int AMODE, int BMODE, class ASrc, class BSrc, class Epi>
-__global__ void __launch_bounds__(kThreads, kWgPerCu)  /* waves per SIMD = resident workgroups per CU (LDS) */
+__global__ void __launch_bounds__(kThreads, wg_per_cu(AMODE, BMODE))
 gemm_tile_kernel(const ASrc a, const BSrc b, const Epi epi, int64_t M, int N, int64_t K, int64_t k_chunk,
                  float* __restrict__ bias_grad /* dW pass only: column sums of A */,
                  int64_t bias_slab_stride /* 0: atomics into bias_grad, else slab z of it */) {
@@ -388,10 +390,10 @@ int launch(const ASrc& a, const BSrc& b, const Epi& e, int64_t M, int N, int64_t
   const int nt = pick_nt(N);
   const int64_t k_chunk = ctr_ceil_div(ctr_ceil_div(K, splits), kBK) * kBK;
   const int zs = (int)ctr_ceil_div(K, k_chunk);
-  // kWgPerCu resident workgroups per CU (LDS), each walking its share of the M tiles
+  // as many workgroups as stay resident, each walking its share of the M tiles
   const int64_t mtiles = ctr_ceil_div(M, kBM);
   const int64_t others = ctr_ceil_div(N, 32 * nt) * zs;
-  int64_t gx = ctr_ceil_div(256 * kWgPerCu, others);
+  int64_t gx = ctr_ceil_div(256 * wg_per_cu(AMODE, BMODE), others);
   if (gx > mtiles) gx = mtiles;
   if (gx < 1) gx = 1;
   const dim3 grid((unsigned)gx, (unsigned)ctr_ceil_div(N, 32 * nt), (unsigned)zs);

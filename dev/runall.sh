@@ -1,4 +1,4 @@
-for w in neuralcf deepfm pnn ffm deepcrossing deepcross widedeep; do
+for w in deepfm pnn deepcrossing deepcross widedeep; do
   python bench.py --workload $w --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/bench_$w.json 2>gpurun_out/bench_$w.err || { echo FAIL $w; tail -5 gpurun_out/bench_$w.err; }
 done
 for w in din dien; do
