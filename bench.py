@@ -170,6 +170,28 @@ def cpu_baseline(name: str, model, budget_s: float = 15.0):
             "ms_per_step": dt * 1e3}
 
 
+def torch_gpu_baseline(name: str, model, device, steps: int = 20):
+    """the same step through plain PyTorch ops on the SAME GPU: oracle/ctr_oracle.py is an op-by-op
+    restatement of the reference's modules (nn.Embedding / matmul / cat / Linear ...), so run on
+    cuda it is what the reference itself executes on this card (eager, hipBLASLt GEMMs, torch's
+    embedding kernels).  Reported next to the CPU baseline; never part of `value`."""
+    from oracle import ctr_oracle as orc  # checker/baseline only, never on the product path
+    batch = batch_of(name)
+    params = {k: v.detach().to(device).clone() for k, v in model.state_dict().items()}
+    inputs, y = make_inputs(name, 0, batch)
+    inputs, y = [t.to(device) for t in inputs], y.to(device)
+    for _ in range(3):
+        orc.step(name, params, inputs, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        orc.step(name, params, inputs, y)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": batch / dt, "unit": "samples/s", "ms_per_step": dt * 1e3, "kind": "port",
+            "what": f"{steps} eager fwd+bwd steps of batch {batch} through oracle/ctr_oracle.py on cuda (plain torch ops)"}
+
+
 # kernel label (ops.py) -> kernel name in the rocprofv3 / PMC summaries under profiles/
 KERNEL_NAMES = {"mlp_fused_bwd": "mlp_bwd_kernel", "mlp_fused_fwd": "mlp_fwd_kernel", "embed_fwd": "embed_fwd_kernel",
                 "embed_bwd": "embed_bwd_kernel", "mf_fwd": "mf_fwd_kernel", "mf_bwd": "mf_bwd_kernel"}
@@ -366,8 +388,14 @@ def main():
                 "ms_per_step": full_ms, "samples_per_s": batch_of(args.workload) / full_ms * 1e3,
                 "what": "zero_grad + forward + BCELoss + backward + Adam(lr=1e-3, weight_decay=1e-5).step()"},
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload in ("neuralcf", "mf", "pnn", "ffm", "deepcrossing", "deepcross", "widedeep", "lr"):
-            out["cpu_baseline"] = cpu_baseline(args.workload, model)
+        if world == 1 and not args.no_cpu_baseline and not args.shard and not args.workload.startswith("gather26"):
+            try:
+                out["torch_gpu_baseline"] = torch_gpu_baseline(args.workload, model, device)
+            except Exception as exc:  # the oracle is CPU test infrastructure first: report, do not fail the bench
+                out["torch_gpu_baseline"] = {"error": repr(exc)[:200]}
+            # the CPU oracle only where a step takes seconds, not minutes (1e6..1e7-row tables, L = 100 histories)
+            if args.workload in ("neuralcf", "mf", "pnn", "ffm", "deepcrossing", "deepcross", "widedeep", "lr"):
+                out["cpu_baseline"] = cpu_baseline(args.workload, model)
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
