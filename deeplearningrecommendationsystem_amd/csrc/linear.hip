@@ -139,6 +139,16 @@ struct SlabEpi {
     ws[(int64_t)blockIdx.z * slab_stride + i * ld + j] = acc;
   }
 };
+// the same for the swapped dW product (tile rows = input features, tile columns = output units):
+// element (i, j) of the tile is gW[j][i]
+struct SlabEpiT {
+  float* ws;
+  int64_t ld;  // = k, the row length of gW
+  int64_t slab_stride;
+  __device__ __forceinline__ void operator()(int64_t i, int64_t j, float acc) const {
+    ws[(int64_t)blockIdx.z * slab_stride + j * ld + i] = acc;
+  }
+};
 struct AtomicEpi {
   float* p;
   int64_t ld;
@@ -232,8 +242,9 @@ __device__ __forceinline__ void read_frag(const float* lds, int r, int h, float 
 template <int NT, int AMODE, int BMODE, class ASrc, class BSrc, class Epi>
 __global__ void __launch_bounds__(kThreads, wg_per_cu(AMODE, BMODE))
 gemm_tile_kernel(const ASrc a, const BSrc b, const Epi epi, int64_t M, int N, int64_t K, int64_t k_chunk,
-                 float* __restrict__ bias_grad /* dW pass only: column sums of A */,
-                 int64_t bias_slab_stride /* 0: atomics into bias_grad, else slab z of it */) {
+                 float* __restrict__ bias_grad /* dW pass only: column sums of A (or of B, see below) */,
+                 int64_t bias_slab_stride /* 0: atomics into bias_grad, else slab z of it */,
+                 int bias_from_b /* swapped dW: gZ is the B operand, its column sums come from the B tile */) {
   constexpr int BN = 32 * NT;
   using AStage = Stager<AMODE, kBM, ASrc>;
   using BStage = Stager<BMODE, BN, BSrc>;
@@ -327,12 +338,17 @@ gemm_tile_kernel(const ASrc a, const BSrc b, const Epi epi, int64_t M, int N, in
 #pragma unroll
         for (int n = 0; n < NT; ++n)
           acc[n][t % CH] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[n][t], acc[n][t % CH], 0, 0, 0);
-      if (bias_grad != nullptr && blockIdx.y == 0 && AMODE == KS) {
-        // A tile is [kk][row]: thread `row` adds its 32 contraction values
-        if (threadIdx.x < kBM) {
+      if (bias_grad != nullptr && AMODE == KS && BMODE == KS) {
+        // the tile of gZ is [kk][row]: thread `row` adds the step's contraction values
+        if (!bias_from_b && blockIdx.y == 0 && threadIdx.x < kBM) {
           constexpr int kKsStride = kBM + 4;
 #pragma unroll 8
           for (int kk = 0; kk < kBK; ++kk) colsum += s_a[cur][kk * kKsStride + threadIdx.x];
+        }
+        if (bias_from_b && tile == 0 && threadIdx.x < BN) {
+          constexpr int kKsStrideB = BN + 4;
+#pragma unroll 8
+          for (int kk = 0; kk < kBK; ++kk) colsum += s_b[cur][kk * kKsStrideB + threadIdx.x];
         }
       }
       __syncthreads();
@@ -354,9 +370,10 @@ gemm_tile_kernel(const ASrc a, const BSrc b, const Epi epi, int64_t M, int N, in
         }
       }
     }
-    if (bias_grad != nullptr && blockIdx.y == 0 && AMODE == KS && threadIdx.x < kBM) {
-      const int64_t i = i0 + threadIdx.x;
-      if (i < M) {
+    if (bias_grad != nullptr && AMODE == KS && BMODE == KS) {
+      const bool mine = bias_from_b ? (tile == 0 && threadIdx.x < BN) : (blockIdx.y == 0 && threadIdx.x < kBM);
+      const int64_t i = (bias_from_b ? j0 : i0) + threadIdx.x;
+      if (mine && i < (bias_from_b ? (int64_t)N : M)) {
         if (bias_slab_stride)
           bias_grad[(int64_t)blockIdx.z * bias_slab_stride + i] = colsum;
         else
@@ -386,7 +403,7 @@ inline int effective_splits(int64_t K, int64_t splits) {
 
 template <int AMODE, int BMODE, class ASrc, class BSrc, class Epi>
 int launch(const ASrc& a, const BSrc& b, const Epi& e, int64_t M, int N, int64_t K, int splits, float* bias_grad,
-           hipStream_t st, int64_t bias_slab_stride = 0) {
+           hipStream_t st, int64_t bias_slab_stride = 0, int bias_from_b = 0) {
   const int nt = pick_nt(N);
   const int64_t k_chunk = ctr_ceil_div(ctr_ceil_div(K, splits), kBK) * kBK;
   const int zs = (int)ctr_ceil_div(K, k_chunk);
@@ -401,15 +418,15 @@ int launch(const ASrc& a, const BSrc& b, const Epi& e, int64_t M, int N, int64_t
   switch (nt) {
     case 1:
       hipLaunchKernelGGL((gemm_tile_kernel<1, AMODE, BMODE, ASrc, BSrc, Epi>), grid, dim3(kThreads), 0, st, a, b, e, M,
-                         N, K, k_chunk, bias_grad, bias_slab_stride);
+                         N, K, k_chunk, bias_grad, bias_slab_stride, bias_from_b);
       break;
     case 2:
       hipLaunchKernelGGL((gemm_tile_kernel<2, AMODE, BMODE, ASrc, BSrc, Epi>), grid, dim3(kThreads), 0, st, a, b, e, M,
-                         N, K, k_chunk, bias_grad, bias_slab_stride);
+                         N, K, k_chunk, bias_grad, bias_slab_stride, bias_from_b);
       break;
     default:
       hipLaunchKernelGGL((gemm_tile_kernel<4, AMODE, BMODE, ASrc, BSrc, Epi>), grid, dim3(kThreads), 0, st, a, b, e, M,
-                         N, K, k_chunk, bias_grad, bias_slab_stride);
+                         N, K, k_chunk, bias_grad, bias_slab_stride, bias_from_b);
       break;
   }
   return ctr_launch_status();
@@ -461,7 +478,10 @@ extern "C" int ctr_linear_bwd(const float* x, int64_t ldx, const float* w, int64
   if (gw || gb) {
     // gW[n][kcol] += sum_m gZ[m][n] X[m][kcol]: contraction = m, split over workgroups
     GzSrc gzt = gz;  // indexed (r = m, c = n): KS operand of the transposed product
-    const int64_t tiles = ctr_ceil_div(n, kBM) * ctr_ceil_div(k, 32 * pick_nt(k));
+    // (tile count of whichever orientation the slab path below will pick)
+    const int64_t tiles_nk = ctr_ceil_div(n, kBM) * ctr_ceil_div(k, 32 * pick_nt(k));
+    const int64_t tiles_kn = ctr_ceil_div(k, kBM) * ctr_ceil_div(n, 32 * pick_nt(n));
+    const int64_t tiles = tiles_kn < tiles_nk ? tiles_kn : tiles_nk;
     // enough row chunks for ~6 resident workgroups per CU: the chunks stream gY, Y and X once
     // and only occupancy hides their HBM latency (256 chunks = 1 workgroup per CU ran 4x slower)
     const int64_t target = tiles >= 4 ? 1024 : 1536;
@@ -483,8 +503,20 @@ extern "C" int ctr_linear_bwd(const float* x, int64_t ldx, const float* w, int64
     const int64_t need = splits * (slab + n);
     if (splits > 8 && workspace && workspace_floats >= need) {
       float* ws_b = workspace + splits * slab;
-      SlabEpi e{workspace, k, slab};
-      int rc = launch<KS, KS>(gzt, plain(x, ldx, m, k), e, n, k, m, (int)splits, gb ? ws_b : nullptr, st, n);
+      // orientation: the 128-row side of the tile should be the longer of (n, k).  A funnel layer
+      // (n = k/2, n < 128) fills half of a 128 x k tile as gZ^T X but all of a k x n tile as X^T gZ.
+      auto padded = [](int64_t rows, int64_t cols) {
+        const int nt = pick_nt((int)cols);
+        return ctr_ceil_div(rows, kBM) * kBM * ctr_ceil_div(cols, 32 * nt) * 32 * nt;
+      };
+      int rc;
+      if (padded(k, n) < padded(n, k)) {
+        SlabEpiT et{workspace, k, slab};
+        rc = launch<KS, KS>(plain(x, ldx, m, k), gzt, et, k, n, m, (int)splits, gb ? ws_b : nullptr, st, n, 1);
+      } else {
+        SlabEpi e{workspace, k, slab};
+        rc = launch<KS, KS>(gzt, plain(x, ldx, m, k), e, n, k, m, (int)splits, gb ? ws_b : nullptr, st, n);
+      }
       if (rc != CTR_OK) return rc;
       CtrSegments segs;
       segs.n = 0;
