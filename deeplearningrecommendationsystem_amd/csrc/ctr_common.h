@@ -120,6 +120,12 @@ int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x,
 int ctr_embed_bwd_bags(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch,
                        const float* gout, int64_t ldo, float* workspace, int64_t workspace_floats,
                        int64_t* used_floats, unsigned char* handled, hipStream_t st);
+// linear_skinny.hip: weight gradient of a layer with few units on both sides over a very long batch
+bool ctr_skinny_dw_ok(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
+                      const float* gw, int64_t ldgw, int64_t m, int n, int k, int act);
+int ctr_skinny_dw(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gy, int64_t ldgy, float* gw,
+                  float* gb, int64_t m, int n, int k, int act, float* workspace, int64_t workspace_floats,
+                  hipStream_t st);
 int ctr_n1_fwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* res, int64_t ldr, float* y,
                int64_t ldy, int64_t m, int k, int act, hipStream_t st);
 int ctr_n1_bwd(const float* x, int64_t ldx, const float* w, const float* y, int64_t ldy, const float* gy, int64_t ldgy,

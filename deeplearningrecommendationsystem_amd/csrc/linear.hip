@@ -465,6 +465,14 @@ extern "C" int ctr_linear_bwd(const float* x, int64_t ldx, const float* w, int64
   if (n == 1 && ctr_n1_supported(k) && (gx || gw || gb))
     return ctr_n1_bwd(x, ldx, w, y, ldy, gy, ldgy, gx, ldgx, accumulate_gx, gw, gb, m, k, act, workspace,
                       workspace_floats, st);
+  // few units on both sides over a long batch: dW streams (linear_skinny.hip); forward and dX stay on
+  // the tile kernel, which beat the streaming variants tried for them
+  if (gw && workspace && ctr_skinny_dw_ok(x, ldx, y, ldy, gy, ldgy, gw, ldgw, m, n, k, act)) {
+    int rc = ctr_skinny_dw(x, ldx, y, ldy, gy, ldgy, gw, gb, m, n, k, act, workspace, workspace_floats, st);
+    if (rc != CTR_OK || !gx) return rc;
+    gw = nullptr;
+    gb = nullptr;
+  }
   GzSrc gz;
   gz.gy = plain(gy, ldgy, m, n);
   gz.y = plain(y ? y : gy, y ? ldy : ldgy, m, n);

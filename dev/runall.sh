@@ -1,8 +1,8 @@
-for w in mf deepfm ffm deepcrossing deepcross widedeep lr; do
+for w in ; do
   python bench.py --workload $w --steps 30 --warmup 5 > gpurun_out/bench_$w.json 2>gpurun_out/bench_$w.err || { echo FAIL $w; tail -5 gpurun_out/bench_$w.err; }
 done
 for w in din dien; do
-  python bench.py --workload $w --steps 5 --warmup 2 > gpurun_out/bench_$w.json 2>gpurun_out/bench_$w.err || { echo FAIL $w; tail -5 gpurun_out/bench_$w.err; }
+  python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_$w.json 2>gpurun_out/bench_$w.err || { echo FAIL $w; tail -5 gpurun_out/bench_$w.err; }
 done
 python - <<'PY'
 import json,glob

@@ -174,6 +174,8 @@ LINEAR_SHAPES = [
     # (m, n, k)
     (1, 1, 1), (37, 5, 3), (64, 32, 32), (129, 33, 31), (1000, 64, 128), (513, 1, 128),
     (300, 128, 96), (2048, 161, 256), (700, 256, 161), (257, 512, 48), (4096, 8, 16),
+    # few units on both sides over a long batch: the streaming kernels of linear_skinny.hip
+    (70001, 48, 16), (65536, 64, 32), (66000, 8, 8), (65537, 4, 16),
 ]
 
 
