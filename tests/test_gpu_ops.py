@@ -434,7 +434,8 @@ def test_embed_backward_padding_row_and_large_table(ops):
     torch.testing.assert_close(grads[id(dtab)][1:].cpu(), ref[1:].float(), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("dim,length,batch", [(16, 20, 100), (4, 1, 5), (8, 33, 70), (64, 5, 9), (5, 3, 3)])
+@pytest.mark.parametrize("dim,length,batch", [(16, 20, 100), (4, 1, 5), (8, 33, 70), (64, 5, 9), (5, 3, 3),
+                                              (16, 50, 1024), (16, 7, 6), (16, 1, 4)])
 def test_gru_recurrence(ops, dim, length, batch):
     g = torch.Generator().manual_seed(dim + length + batch)
     gru = torch.nn.GRU(dim, dim, batch_first=True)
