@@ -44,6 +44,7 @@ class GradBucket:
         self._flat = None       # packing bucket, allocated on first use
         self._views = None
         self._shared = {}       # storage data_ptr -> flat fp32 view of the whole storage
+        self._plan = None       # (key of the gradient tensors, storages) of the previous step
 
     def _pack_bucket(self):
         if self._flat is None:
@@ -88,7 +89,17 @@ class GradBucket:
         """average gradients over the ranks (no-op for a single process)"""
         if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
             return
-        shared = self._shared_storages()
+        # hipGraph replay rewrites the same static .grad tensors every step: the storages found once
+        # stay valid as long as the first and last gradients are still the same tensors
+        first, last = self.params[0].grad, self.params[-1].grad
+        key = (id(first), id(last), first.data_ptr() if first is not None else 0)
+        if self._plan is not None and self._plan[0] == key:
+            shared = self._plan[1]
+        else:
+            shared = self._shared_storages()
+            # (the cached views keep their storage alive: only worth it, and only harmless, when small)
+            small = shared is not None and sum(f.numel() for f in shared) <= (1 << 24)
+            self._plan = (key, shared) if small else None
         if shared is not None:
             for flat in shared:
                 self._mean(flat, group)
