@@ -241,7 +241,7 @@ int ctr_n1_bwd(const float* x, int64_t ldx, const float* w, const float* y, int6
   int grid = ctr_stream_grid(m * lpr, kBlock);
   if (grid > 1024) grid = 1024;
   const bool slabs = gw && ws && ws_floats >= (int64_t)grid * (k + 1) && grid > 8;
-  if (!slabs && grid > 128) grid = 128;  // same-address atomics serialise: keep the chains short
+  if ((gw || gb) && !slabs && grid > 128) grid = 128;  // same-address atomics serialise: keep the chains short
   N1BwdArgs a{x, ldx, w, y, ldy, gy, ldgy, gx, ldgx, accumulate_gx, gw, gb, m, k, act, lpr, slabs ? ws : nullptr};
   const bool single = (vec ? 4 : 1) * lpr >= k && x && w;  // one chunk per lane: 4 rows in flight
   if (vec && single)

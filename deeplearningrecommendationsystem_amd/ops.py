@@ -355,6 +355,8 @@ def mlp_fwd(x: torch.Tensor, layers: Sequence[Layer], last_out: Optional[torch.T
         if rc not in _REFUSED:
             _lib.check(rc, "ctr_mlp_fwd")
             return [x] + ys
+        if _profiler is not None and _profiler.records and _profiler.records[-1][0] == "mlp_fused_fwd":
+            _profiler.records.pop()  # refused: nothing ran
     acts = [x]
     for k, layer in enumerate(layers):
         out = last_out if (k == len(layers) - 1) else None
@@ -395,6 +397,8 @@ def mlp_bwd(acts: Sequence[torch.Tensor], layers: Sequence[Layer], gy: torch.Ten
         if rc not in _REFUSED:
             _lib.check(rc, "ctr_mlp_bwd")
             return grads, gx
+        if _profiler is not None and _profiler.records and _profiler.records[-1][0] == "mlp_fused_bwd":
+            _profiler.records.pop()  # refused: nothing ran, the per-layer path below is what gets timed
     g = gy
     for k in range(len(layers) - 1, -1, -1):
         layer = layers[k]
