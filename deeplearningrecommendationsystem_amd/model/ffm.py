@@ -7,7 +7,7 @@ from torch.nn.init import xavier_normal_
 
 from .. import ops
 from ..ops import FieldSpec
-from .._lib import FIELD_BAG, FIELD_ID_F32
+from .._lib import FIELD_BAG, FIELD_ID_F32, FIELD_ID_I64
 from ._base import FeatureModel
 
 # the 12 field-aware vectors in buffer order, and the reference's 15 dot products
@@ -28,20 +28,32 @@ _SOURCE = {"age": (FIELD_BAG, 2, 1), "gender": (FIELD_BAG, 3, 2), "occupation": 
            "movie": (FIELD_BAG, 26, 19), "userid": (FIELD_ID_F32, 0, 0), "itemid": (FIELD_ID_F32, 1, 0)}
 
 
+SHARDED = ("userid_user", "userid_item", "itemid_user", "itemid_item")  # the tables indexed by user / item id
+
+
 class FFM(FeatureModel):
     """``FFM(num_feature, num_vector)``; ``forward(x: (B,45)) -> (B,1)``.
-    ``num_users`` / ``num_items`` (keyword-only, reference values hard-coded at
-    model/ffm.py:19-26) allow the larger id vocabularies of BASELINE configs[3]."""
+    Keyword-only extensions: ``num_users`` / ``num_items`` (reference values hard-coded at
+    model/ffm.py:19-26) allow the larger id vocabularies of BASELINE configs[3];
+    ``sharded=True`` deals the rows of the four field-aware id tables round-robin to the ranks
+    of ``group`` (dist.ShardedEmbedding: lookups through all-to-all)."""
 
-    def __init__(self, num_feature: int, num_vector: int, *, num_users: int = 943, num_items: int = 1682):
+    def __init__(self, num_feature: int, num_vector: int, *, num_users: int = 943, num_items: int = 1682,
+                 sharded: bool = False, group=None):
         super().__init__()
+        self.sharded = bool(sharded)
         vocab = {"age": 1, "gender": 2, "occupation": 21, "movie": 19, "userid": num_users, "itemid": num_items}
         for name in VECTORS:
-            setattr(self, name, nn.Embedding(vocab[name.split("_")[0]], num_vector))
+            if sharded and name in SHARDED:
+                from ..dist import ShardedEmbedding
+                setattr(self, name, ShardedEmbedding(vocab[name.split("_")[0]], num_vector, group=group))
+            else:
+                setattr(self, name, nn.Embedding(vocab[name.split("_")[0]], num_vector))
+                xavier_normal_(getattr(self, name).weight.data)
         self.user = nn.Embedding(num_users, 1)
         self.item = nn.Embedding(num_items, 1)
         self.linear = nn.Linear(num_feature, 1, True)
-        for name in VECTORS + ("user", "item"):
+        for name in ("user", "item"):
             xavier_normal_(getattr(self, name).weight.data)
 
     def _params(self):
@@ -49,14 +61,26 @@ class FFM(FeatureModel):
                                                               self.linear.weight, self.linear.bias]
 
     def forward(self, feature_vector):
-        return self._run_model(feature_vector, self._params())
+        params = self._params()
+        if self.sharded:
+            # rows of this batch through the exchange; the kernels then see each of them as a
+            # (B, k) table indexed 0..B-1, and its gradient flows back through the exchange
+            self._need_device(feature_vector, params[12])
+            uid, iid = feature_vector[:, 0].long(), feature_vector[:, 1].long()
+            for k, name in enumerate(VECTORS):
+                if name in SHARDED:
+                    params[k] = getattr(self, name)(uid if name.startswith("userid") else iid)
+        return self._run_model(feature_vector, params)
 
-    @staticmethod
-    def _specs(tables, dim):
+    def _specs(self, tables, dim):
         specs = []
         for k, (name, table) in enumerate(zip(VECTORS, tables)):
             kind, col, bag = _SOURCE[name.split("_")[0]]
-            specs.append(FieldSpec(kind, dim, k * dim, table=table, src_col=col, bag_size=bag))
+            if self.sharded and name in SHARDED:
+                pos = torch.arange(table.shape[0], device=table.device, dtype=torch.int64)
+                specs.append(FieldSpec(FIELD_ID_I64, dim, k * dim, table=table, idx=pos))
+            else:
+                specs.append(FieldSpec(kind, dim, k * dim, table=table, src_col=col, bag_size=bag))
         return specs
 
     def run_forward(self, inputs, params):
@@ -75,7 +99,15 @@ class FFM(FeatureModel):
         tables, (user1, item1, lin_w, lin_b) = params[:12], params[12:16]
         batch, dim = x.shape[0], tables[0].shape[1]
         gemb = torch.empty_like(emb)
-        zeros = ops.zero_grads(params)
+        if self.sharded:
+            # exchanged rows are activations: their gradients stay out of the flat buffer that the
+            # data-parallel all-reduce works on
+            rows = [k for k, name in enumerate(VECTORS) if name in SHARDED]
+            zeros = ops.zero_grads([p for k, p in enumerate(params) if k not in rows])
+            for k in rows:
+                zeros[id(params[k])] = torch.zeros_like(params[k])
+        else:
+            zeros = ops.zero_grads(params)
         g_user1, g_item1, g_w, g_b = (zeros[id(t)] for t in (user1, item1, lin_w, lin_b))
         ops.ffm_head_bwd(emb, 12, dim, PAIRS, x, user1, item1, lin_w, lin_b, prob, gprob.view(batch, 1),
                          g_user1, g_item1, g_w, g_b, gemb)
