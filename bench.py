@@ -49,6 +49,7 @@ WORKLOADS = {
     "deepcross": "deepcross (DCN) 3 cross layers, deep=[512,256,128,1] emb=128 (d=641) ml-100k vocab batch=65536/gpu",
     "widedeep": "widedeep hidden=[512,256,128,1] emb=128 ml-100k vocab batch=65536/gpu",
     "lr": "lr 43 features ml-100k vocab batch=65536/gpu",
+    "nfm": "nfm hidden=[512,256,128,1] emb=128 ml-100k vocab batch=65536/gpu",
     # the embedding stage alone at the roofline shape of SURVEY.md 8(d) cfg3b (metric ii: gather GB/s)
     "gather26": "embedding stage 26 fields x 1e6 rows x emb=16 batch=65536/gpu, uniform ids (gather fwd + dense-grad scatter bwd)",
     "gather26zipf": "embedding stage 26 fields x 1e6 rows x emb=16 batch=65536/gpu, Zipf(1.05) ids",
@@ -63,7 +64,7 @@ def make_inputs(name: str, rank: int, batch: int):
         return [u, i], synth.labels(batch, name != "mf", gen)
     if name in ("deepfm",):
         return [synth.feature_batch(batch, 1_000_000, 1_000_000, gen)], synth.labels(batch, True, gen)
-    if name in ("pnn", "ffm", "deepcrossing", "deepcross", "widedeep", "lr"):
+    if name in ("pnn", "ffm", "deepcrossing", "deepcross", "widedeep", "lr", "nfm"):
         return [synth.feature_batch(batch, gen=gen)], synth.labels(batch, True, gen)
     if name in ("din", "dien"):
         hist, target = synth.hist_batch(batch, 100, 10_000_000, gen)
@@ -113,6 +114,8 @@ def make_model(name: str, shard: bool = False):
         return zoo.WideDeep(943, 1682, [512, 256, 128, 1], 128)       # scripts/widedeep.py
     if name == "lr":
         return zoo.LogisticRegression(943, 1682, 43)                  # scripts/lr.py
+    if name == "nfm":
+        return zoo.NFM(943, 1682, [512, 256, 128, 1], 128)            # scripts/nfm.py:53
     if name in ("gather26", "gather26zipf"):
         return zoo.EmbeddingStage(26, 1_000_000, 16)
     raise SystemExit(f"unknown workload {name}")
@@ -404,7 +407,7 @@ def main():
             except Exception as exc:  # the oracle is CPU test infrastructure first: report, do not fail the bench
                 out["torch_gpu_baseline"] = {"error": repr(exc)[:200]}
             # the CPU oracle only where a step takes seconds, not minutes (1e6..1e7-row tables, L = 100 histories)
-            if args.workload in ("neuralcf", "mf", "pnn", "ffm", "deepcrossing", "deepcross", "widedeep", "lr"):
+            if args.workload in ("neuralcf", "mf", "pnn", "ffm", "deepcrossing", "deepcross", "widedeep", "lr", "nfm"):
                 out["cpu_baseline"] = cpu_baseline(args.workload, model)
         print(json.dumps(out))
     if dist.is_initialized():

@@ -664,3 +664,73 @@ extern "C" int ctr_act_bwd(const float* y, int64_t ldy, const float* gy, int64_t
                      gy, ldgy, out, ldo, m, n, act, accumulate);
   return ctr_launch_status();
 }
+
+
+// ---------------------------------------------------------------------------
+// NFM bi-interaction pooling (model/nfm.py:56-61): out[b, e] = sum_{i<j} v_i[e] * v_j[e] over the
+// nvec vectors of a sample, summed in the reference's pair order (the (sum v)^2 - sum v^2 identity
+// would cancel digits the parity bar wants).  Backward: gemb[b, i, e] (= or +=) g[b, e] * (S[e] -
+// v_i[e]).  Streaming: a lane owns one (sample, element) column.
+namespace {
+
+constexpr int kBiBlock = 256;
+
+__global__ void __launch_bounds__(kBiBlock)
+biinteract_fwd_kernel(const float* __restrict__ emb, int64_t lde, int64_t batch, int nvec, int dim,
+                      float* __restrict__ out, int64_t ldo) {
+  const int64_t total = batch * dim;
+  for (int64_t g = (int64_t)blockIdx.x * kBiBlock + threadIdx.x; g < total; g += (int64_t)gridDim.x * kBiBlock) {
+    const int64_t b = g / dim;
+    const int e = (int)(g - b * dim);
+    const float* v = emb + b * lde + e;
+    float acc = 0.0f;
+    for (int i = 0; i < nvec; ++i) {
+      const float vi = v[(int64_t)i * dim];
+      for (int j = i + 1; j < nvec; ++j) acc += vi * v[(int64_t)j * dim];
+    }
+    out[b * ldo + e] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(kBiBlock)
+biinteract_bwd_kernel(const float* __restrict__ emb, int64_t lde, int64_t batch, int nvec, int dim,
+                      const float* __restrict__ gout, int64_t ldgo, float* __restrict__ gemb, int64_t ldg,
+                      int accumulate) {
+  const int64_t total = batch * dim;
+  for (int64_t g = (int64_t)blockIdx.x * kBiBlock + threadIdx.x; g < total; g += (int64_t)gridDim.x * kBiBlock) {
+    const int64_t b = g / dim;
+    const int e = (int)(g - b * dim);
+    const float* v = emb + b * lde + e;
+    float sum = 0.0f;
+    for (int i = 0; i < nvec; ++i) sum += v[(int64_t)i * dim];
+    const float go = gout[b * ldgo + e];
+    float* o = gemb + b * ldg + e;
+    for (int i = 0; i < nvec; ++i) {
+      const float val = go * (sum - v[(int64_t)i * dim]);
+      o[(int64_t)i * dim] = accumulate ? o[(int64_t)i * dim] + val : val;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int ctr_biinteract_fwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim, float* out,
+                                  int64_t ldo, void* stream) {
+  CTR_REQUIRE(batch >= 0, CTR_EINVAL);
+  if (batch == 0) return CTR_OK;
+  CTR_REQUIRE(emb && out && nvec >= 1 && nvec <= 64 && dim > 0 && lde >= (int64_t)nvec * dim && ldo >= dim, CTR_EINVAL);
+  hipLaunchKernelGGL(biinteract_fwd_kernel, dim3(ctr_stream_grid(batch * dim, kBiBlock)), dim3(kBiBlock), 0,
+                     (hipStream_t)stream, emb, lde, batch, nvec, dim, out, ldo);
+  return ctr_launch_status();
+}
+
+extern "C" int ctr_biinteract_bwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim, const float* gout,
+                                  int64_t ldgo, float* gemb, int64_t ldg, int accumulate, void* stream) {
+  CTR_REQUIRE(batch >= 0, CTR_EINVAL);
+  if (batch == 0) return CTR_OK;
+  CTR_REQUIRE(emb && gout && gemb && nvec >= 1 && nvec <= 64 && dim > 0, CTR_EINVAL);
+  CTR_REQUIRE(lde >= (int64_t)nvec * dim && ldg >= (int64_t)nvec * dim && ldgo >= dim, CTR_EINVAL);
+  hipLaunchKernelGGL(biinteract_bwd_kernel, dim3(ctr_stream_grid(batch * dim, kBiBlock)), dim3(kBiBlock), 0,
+                     (hipStream_t)stream, emb, lde, batch, nvec, dim, gout, ldgo, gemb, ldg, accumulate);
+  return ctr_launch_status();
+}

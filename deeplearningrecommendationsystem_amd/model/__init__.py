@@ -13,5 +13,6 @@ from .embedding_stage import EmbeddingStage
 from .deepcross import DeepCross
 from .widedeep import WideDeep
 from .lr import LogisticRegression
+from .nfm import NFM
 
-__all__ = ["MatrixFactorization", "NeuralCF", "DeepFM", "PNN", "FFM", "DeepCrossing", "DIN", "DIEN", "EmbeddingStage", "DeepCross", "WideDeep", "LogisticRegression"]
+__all__ = ["MatrixFactorization", "NeuralCF", "DeepFM", "PNN", "FFM", "DeepCrossing", "DIN", "DIEN", "EmbeddingStage", "DeepCross", "WideDeep", "LogisticRegression", "NFM"]

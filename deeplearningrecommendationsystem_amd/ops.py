@@ -519,6 +519,26 @@ def act_bwd(y, gy, act: int, out, accumulate: bool) -> None:
     _lib.check(rc, "ctr_act_bwd")
 
 
+def biinteract_fwd(emb, nvec, dim, out) -> torch.Tensor:
+    """NFM bi-interaction: out[b, e] = sum_{i<j} v_i[e] * v_j[e]"""
+    emb, out = _mat(emb, "emb"), _mat(out, "out")
+    batch = emb.shape[0]
+    rc = _timed("biinteract_fwd", lambda: (4 * batch * (nvec + 1) * dim, batch * dim * nvec * (nvec - 1)),
+                _lib.load().ctr_biinteract_fwd, emb.data_ptr(), _ld(emb), batch, nvec, dim, out.data_ptr(), _ld(out),
+                _lib.stream_ptr())
+    _lib.check(rc, "ctr_biinteract_fwd")
+    return out
+
+
+def biinteract_bwd(emb, nvec, dim, gout, gemb, accumulate: bool) -> None:
+    emb, gout, gemb = _mat(emb, "emb"), _mat(gout, "gout"), _mat(gemb, "gemb")
+    batch = emb.shape[0]
+    rc = _timed("biinteract_bwd", lambda: (4 * batch * ((2 + int(accumulate)) * nvec + 1) * dim, 3 * batch * dim * nvec),
+                _lib.load().ctr_biinteract_bwd, emb.data_ptr(), _ld(emb), batch, nvec, dim, gout.data_ptr(), _ld(gout),
+                gemb.data_ptr(), _ld(gemb), int(accumulate), _lib.stream_ptr())
+    _lib.check(rc, "ctr_biinteract_bwd")
+
+
 def cross_fwd(x0, u, xl, bias, out) -> torch.Tensor:
     """Deep & Cross combine: out = x0 * u + bias + xl"""
     x0, u, xl, out = _mat(x0, "x0"), _mat(u, "u"), _mat(xl, "xl"), _mat(out, "out")

@@ -147,6 +147,13 @@ int ctr_allpairs_fwd(const float* emb, int64_t lde, int64_t batch, int nvec, int
 int ctr_allpairs_bwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim,
                      const float* gp, int64_t ldgp, float* gemb, int64_t ldg, int accumulate, void* stream);
 
+/* NFM bi-interaction pooling (model/nfm.py:56-61): out[b, e] = sum_{i<j} v_i[e] * v_j[e], pairs in
+ * the reference's order; emb as for ctr_allpairs_fwd.  bwd: gemb[b,i,e] (= or +=) g[b,e] * sum_{j!=i} v_j[e]. */
+int ctr_biinteract_fwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim,
+                       float* out, int64_t ldo, void* stream);
+int ctr_biinteract_bwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim,
+                       const float* gout, int64_t ldgo, float* gemb, int64_t ldg, int accumulate, void* stream);
+
 /* DeepFM wide part + FM second order (model/deepfm.py:63,71-77):
  *   out[b*ldo] = user1[u] + item1[i] + (x[b, dense_col0..+ndense) . wide_w + wide_b)
  *               + 0.5 * sum_e[(sum_f v_fe)^2 - sum_f v_fe^2]

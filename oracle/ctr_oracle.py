@@ -252,6 +252,25 @@ def widedeep_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
     return torch.sigmoid(_lin(p, "output", torch.cat([wide, deep], dim=1)))
 
 
+def nfm_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
+    """model/nfm.py:43-73: six vectors as DeepFM; bi-interaction ``sum_{i<j} f_i * f_j`` (:58-61,
+    element products summed in pair order) -> ``linear`` WITHOUT activation (:62) -> Linear+ReLU
+    per pair (:63-65); wide = user(u) + item(i) + Linear(43,1)(x[:,2:]) (:54);
+    sigmoid(Linear(2,1)(cat(wide, deep))) -> (B,1)"""
+    f = six_field_vectors(p, x, ("user_embedding", "item_embedding", "age_embedding", "gender_embedding",
+                                 "occupation_embedding", "movie_embedding"))
+    cross = 0.0
+    for i in range(len(f)):
+        for j in range(i + 1, len(f)):
+            cross = cross + f[i] * f[j]
+    deep = _lin(p, "linear", cross)
+    for k in range(_count(p, "dnn_network")):
+        deep = torch.relu(_lin(p, f"dnn_network.{k}", deep))
+    uid, iid = ids_from_float(x[:, COL_USER]), ids_from_float(x[:, COL_ITEM])
+    wide = _emb(p, "user", uid) + _emb(p, "item", iid) + _lin(p, "wide", x[:, 2:])
+    return torch.sigmoid(_lin(p, "output", torch.cat([wide, deep], dim=1)))
+
+
 def lr_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
     """model/lr.py:24-25: sigmoid(user(u) + item(i) + Linear(43,1)(x[:,2:])) -> (B,1)"""
     uid, iid = ids_from_float(x[:, COL_USER]), ids_from_float(x[:, COL_ITEM])
@@ -350,7 +369,7 @@ def bce_loss(prob: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
 FORWARDS: Dict[str, Callable[..., torch.Tensor]] = {
     "mf": mf_forward, "neuralcf": neuralcf_forward, "ffm": ffm_forward, "pnn": pnn_forward,
     "deepcrossing": deepcrossing_forward, "deepfm": deepfm_forward, "din": din_forward,
-    "dien": dien_forward, "deepcross": deepcross_forward, "widedeep": widedeep_forward, "lr": lr_forward,
+    "dien": dien_forward, "deepcross": deepcross_forward, "widedeep": widedeep_forward, "lr": lr_forward, "nfm": nfm_forward,
 }
 
 

@@ -41,9 +41,10 @@ def _ref_classes():
     from model.deepcross import DeepCross
     from model.widedeep import WideDeep
     from model.lr import LogisticRegression
+    from model.nfm import NFM
     return dict(mf=MatrixFactorization, neuralcf=NeuralCF, ffm=FFM, pnn=PNN,
                 deepcrossing=DeepCrossing, deepfm=DeepFM, din=DIN, dien=DIEN,
-                deepcross=DeepCross, widedeep=WideDeep, lr=LogisticRegression)
+                deepcross=DeepCross, widedeep=WideDeep, lr=LogisticRegression, nfm=NFM)
 
 
 # name -> (model key, ctor args, ctor kwargs, input builder(gen) -> (inputs, y))
@@ -99,6 +100,9 @@ def _cases():
     c["deepcross_b37"] = ("deepcross", (5, 7, 2, [16, 8], 4), {}, feats(37, 5, 7), 2)
     c["widedeep_b37"] = ("widedeep", (5, 7, [16, 1], 4), {}, feats(37, 5, 7), 2)
     c["lr_b37"] = ("lr", (5, 7, 43), {}, feats(37, 5, 7), 2)
+    for s in (0, 1):
+        c[f"nfm_s{s}"] = ("nfm", (30, 40, [32, 16, 1], 8), {}, feats(64, 30, 40, 4), s)
+    c["nfm_b37"] = ("nfm", (5, 7, [16, 1], 4), {}, feats(37, 5, 7), 2)
     return c
 
 

@@ -390,6 +390,26 @@ def test_din_pair_operand_and_folded_first_layer(ops, dim, length, batch):
     torch.testing.assert_close(gw.cpu(), wl.grad.float(), rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("batch,nvec,dim", [(1000, 6, 8), (37, 6, 128), (5, 2, 3), (4096, 12, 16)])
+def test_bi_interaction_pooling(ops, batch, nvec, dim):
+    # model/nfm.py:56-61: sum of the element products of every pair of vectors, and its backward
+    g = torch.Generator().manual_seed(batch + nvec + dim)
+    emb = torch.randn(batch, nvec * dim, generator=g)
+    out = torch.empty(batch, dim, device=DEV)
+    ops.biinteract_fwd(emb.to(DEV), nvec, dim, out)
+    leaf = emb.double().requires_grad_(True)
+    v = leaf.view(batch, nvec, dim)
+    ref = sum(v[:, i] * v[:, j] for i in range(nvec) for j in range(i + 1, nvec))
+    torch.testing.assert_close(out.cpu(), ref.float(), rtol=1e-5, atol=1e-5)
+    gout = torch.randn(batch, dim, generator=g)
+    ref.backward(gout.double())
+    gemb = torch.full((batch, nvec * dim), float("nan"), device=DEV)
+    ops.biinteract_bwd(emb.to(DEV), nvec, dim, gout.to(DEV), gemb, accumulate=False)
+    torch.testing.assert_close(gemb.cpu(), leaf.grad.float(), rtol=1e-5, atol=1e-5)
+    ops.biinteract_bwd(emb.to(DEV), nvec, dim, gout.to(DEV), gemb, accumulate=True)
+    torch.testing.assert_close(gemb.cpu(), 2 * leaf.grad.float(), rtol=1e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize("m,d", [(1000, 41), (257, 64), (3, 5), (4096, 641)])
 def test_cross_layer_combine(ops, m, d):
     # model/deepcross.py:14-17: x_{l+1} = x0 * u + b + x_l and its backward pieces
