@@ -50,6 +50,7 @@ WORKLOADS = {
     "widedeep": "widedeep hidden=[512,256,128,1] emb=128 ml-100k vocab batch=65536/gpu",
     "lr": "lr 43 features ml-100k vocab batch=65536/gpu",
     "nfm": "nfm hidden=[512,256,128,1] emb=128 ml-100k vocab batch=65536/gpu",
+    "afm": "afm emb=128 attention=64 ml-100k vocab batch=65536/gpu",
     # the embedding stage alone at the roofline shape of SURVEY.md 8(d) cfg3b (metric ii: gather GB/s)
     "gather26": "embedding stage 26 fields x 1e6 rows x emb=16 batch=65536/gpu, uniform ids (gather fwd + dense-grad scatter bwd)",
     "gather26zipf": "embedding stage 26 fields x 1e6 rows x emb=16 batch=65536/gpu, Zipf(1.05) ids",
@@ -64,7 +65,7 @@ def make_inputs(name: str, rank: int, batch: int):
         return [u, i], synth.labels(batch, name != "mf", gen)
     if name in ("deepfm",):
         return [synth.feature_batch(batch, 1_000_000, 1_000_000, gen)], synth.labels(batch, True, gen)
-    if name in ("pnn", "ffm", "deepcrossing", "deepcross", "widedeep", "lr", "nfm"):
+    if name in ("pnn", "ffm", "deepcrossing", "deepcross", "widedeep", "lr", "nfm", "afm"):
         return [synth.feature_batch(batch, gen=gen)], synth.labels(batch, True, gen)
     if name in ("din", "dien"):
         hist, target = synth.hist_batch(batch, 100, 10_000_000, gen)
@@ -114,6 +115,8 @@ def make_model(name: str, shard: bool = False):
         return zoo.WideDeep(943, 1682, [512, 256, 128, 1], 128)       # scripts/widedeep.py
     if name == "lr":
         return zoo.LogisticRegression(943, 1682, 43)                  # scripts/lr.py
+    if name == "afm":
+        return zoo.AFM(943, 1682, 128, 64)                            # scripts/afm.py:52
     if name == "nfm":
         return zoo.NFM(943, 1682, [512, 256, 128, 1], 128)            # scripts/nfm.py:53
     if name in ("gather26", "gather26zipf"):
@@ -407,7 +410,7 @@ def main():
             except Exception as exc:  # the oracle is CPU test infrastructure first: report, do not fail the bench
                 out["torch_gpu_baseline"] = {"error": repr(exc)[:200]}
             # the CPU oracle only where a step takes seconds, not minutes (1e6..1e7-row tables, L = 100 histories)
-            if args.workload in ("neuralcf", "mf", "pnn", "ffm", "deepcrossing", "deepcross", "widedeep", "lr", "nfm"):
+            if args.workload in ("neuralcf", "mf", "pnn", "ffm", "deepcrossing", "deepcross", "widedeep", "lr", "nfm", "afm"):
                 out["cpu_baseline"] = cpu_baseline(args.workload, model)
         print(json.dumps(out))
     if dist.is_initialized():

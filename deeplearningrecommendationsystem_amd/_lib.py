@@ -73,6 +73,8 @@ SIGNATURES = {
     "ctr_act_bwd": (_i, [_p, _l, _p, _l, _p, _l, _l, _i, _i, _i, _p]),
     "ctr_biinteract_fwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _p]),
     "ctr_biinteract_bwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _p, _l, _i, _p]),
+    "ctr_pairprod_fwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _p]),
+    "ctr_pairprod_bwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _p, _p, _l, _p, _l, _i, _p]),
     "ctr_cross_fwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _p, _l, _l, _i, _p]),
     "ctr_cross_bwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _p, _l, _p, _l, _i, _p, _l, _p]),
     "ctr_din_concat_fwd": (_i, [_p, _l, _i, _p, _p, _l, _i, _p, _l, _p, _l, _i, _p, _p]),

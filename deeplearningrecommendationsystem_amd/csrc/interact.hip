@@ -734,3 +734,85 @@ extern "C" int ctr_biinteract_bwd(const float* emb, int64_t lde, int64_t batch, 
                      (hipStream_t)stream, emb, lde, batch, nvec, dim, gout, ldgo, gemb, ldg, accumulate);
   return ctr_launch_status();
 }
+
+
+// ---------------------------------------------------------------------------
+// AFM pair products (model/afm.py:56-60): out[(b*np + idx(i,j)), e] = v_i[e] * v_j[e], i < j in
+// lexicographic order, np = nvec*(nvec-1)/2 rows per sample -- the operand of the attention
+// net.  Backward: the pair gradient is gp (through the attention net) plus, when given,
+// attn[b, p] * gpool[b, :] (through the attention-weighted sum, afm.py:65); then
+// gemb[b, i, e] (= or +=) sum_{j != i} gpair[b, idx(i,j), e] * v_j[e].
+namespace {
+
+__global__ void __launch_bounds__(kBiBlock)
+pairprod_fwd_kernel(const float* __restrict__ emb, int64_t lde, int64_t batch, int nvec, int dim,
+                    float* __restrict__ out, int64_t ldo) {
+  const int np = nvec * (nvec - 1) / 2;
+  const int64_t total = batch * dim;
+  for (int64_t g = (int64_t)blockIdx.x * kBiBlock + threadIdx.x; g < total; g += (int64_t)gridDim.x * kBiBlock) {
+    const int64_t b = g / dim;
+    const int e = (int)(g - b * dim);
+    const float* v = emb + b * lde + e;
+    float* o = out + b * np * ldo + e;
+    int p = 0;
+    for (int i = 0; i < nvec; ++i) {
+      const float vi = v[(int64_t)i * dim];
+      for (int j = i + 1; j < nvec; ++j, ++p) o[(int64_t)p * ldo] = vi * v[(int64_t)j * dim];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kBiBlock)
+pairprod_bwd_kernel(const float* __restrict__ emb, int64_t lde, int64_t batch, int nvec, int dim,
+                    const float* __restrict__ gp, int64_t ldgp, const float* __restrict__ attn,
+                    const float* __restrict__ gpool, int64_t ldgo, float* __restrict__ gemb, int64_t ldg,
+                    int accumulate) {
+  const int np = nvec * (nvec - 1) / 2;
+  const int64_t total = batch * dim;
+  for (int64_t g = (int64_t)blockIdx.x * kBiBlock + threadIdx.x; g < total; g += (int64_t)gridDim.x * kBiBlock) {
+    const int64_t b = g / dim;
+    const int e = (int)(g - b * dim);
+    const float* v = emb + b * lde + e;
+    const float* q = gp + b * np * ldgp + e;
+    const float go = (attn && gpool) ? gpool[b * ldgo + e] : 0.0f;
+    float acc[16];  // nvec <= 16 (checked on the host); only the first nvec are live
+    for (int i = 0; i < nvec; ++i) acc[i] = 0.0f;
+    int p = 0;
+    for (int i = 0; i < nvec; ++i) {
+      const float vi = v[(int64_t)i * dim];
+      for (int j = i + 1; j < nvec; ++j, ++p) {
+        float gpair = q[(int64_t)p * ldgp];
+        if (attn && gpool) gpair = fmaf(attn[b * np + p], go, gpair);
+        acc[i] = fmaf(gpair, v[(int64_t)j * dim], acc[i]);
+        acc[j] = fmaf(gpair, vi, acc[j]);
+      }
+    }
+    float* o = gemb + b * ldg + e;
+    for (int i = 0; i < nvec; ++i) o[(int64_t)i * dim] = accumulate ? o[(int64_t)i * dim] + acc[i] : acc[i];
+  }
+}
+
+}  // namespace
+
+extern "C" int ctr_pairprod_fwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim, float* out,
+                                int64_t ldo, void* stream) {
+  CTR_REQUIRE(batch >= 0, CTR_EINVAL);
+  if (batch == 0) return CTR_OK;
+  CTR_REQUIRE(emb && out && nvec >= 2 && nvec <= 16 && dim > 0 && lde >= (int64_t)nvec * dim && ldo >= dim, CTR_EINVAL);
+  hipLaunchKernelGGL(pairprod_fwd_kernel, dim3(ctr_stream_grid(batch * dim, kBiBlock)), dim3(kBiBlock), 0,
+                     (hipStream_t)stream, emb, lde, batch, nvec, dim, out, ldo);
+  return ctr_launch_status();
+}
+
+extern "C" int ctr_pairprod_bwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim, const float* gp,
+                                int64_t ldgp, const float* attn, const float* gpool, int64_t ldgo, float* gemb,
+                                int64_t ldg, int accumulate, void* stream) {
+  CTR_REQUIRE(batch >= 0, CTR_EINVAL);
+  if (batch == 0) return CTR_OK;
+  CTR_REQUIRE(emb && gp && gemb && nvec >= 2 && nvec <= 16 && dim > 0, CTR_EINVAL);
+  CTR_REQUIRE(lde >= (int64_t)nvec * dim && ldg >= (int64_t)nvec * dim && ldgp >= dim, CTR_EINVAL);
+  CTR_REQUIRE((attn == nullptr) == (gpool == nullptr) && (!gpool || ldgo >= dim), CTR_EINVAL);
+  hipLaunchKernelGGL(pairprod_bwd_kernel, dim3(ctr_stream_grid(batch * dim, kBiBlock)), dim3(kBiBlock), 0,
+                     (hipStream_t)stream, emb, lde, batch, nvec, dim, gp, ldgp, attn, gpool, ldgo, gemb, ldg, accumulate);
+  return ctr_launch_status();
+}

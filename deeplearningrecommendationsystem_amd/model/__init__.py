@@ -14,5 +14,6 @@ from .deepcross import DeepCross
 from .widedeep import WideDeep
 from .lr import LogisticRegression
 from .nfm import NFM
+from .afm import AFM
 
-__all__ = ["MatrixFactorization", "NeuralCF", "DeepFM", "PNN", "FFM", "DeepCrossing", "DIN", "DIEN", "EmbeddingStage", "DeepCross", "WideDeep", "LogisticRegression", "NFM"]
+__all__ = ["MatrixFactorization", "NeuralCF", "DeepFM", "PNN", "FFM", "DeepCrossing", "DIN", "DIEN", "EmbeddingStage", "DeepCross", "WideDeep", "LogisticRegression", "NFM", "AFM"]

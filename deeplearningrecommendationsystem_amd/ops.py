@@ -539,6 +539,29 @@ def biinteract_bwd(emb, nvec, dim, gout, gemb, accumulate: bool) -> None:
     _lib.check(rc, "ctr_biinteract_bwd")
 
 
+def pairprod_fwd(emb, nvec, dim, out) -> torch.Tensor:
+    """AFM: out[(b*np + idx(i,j)), :] = v_i * v_j for every pair i < j"""
+    emb, out = _mat(emb, "emb"), _mat(out, "out")
+    batch, npairs = emb.shape[0], nvec * (nvec - 1) // 2
+    rc = _timed("pairprod_fwd", lambda: (4 * batch * (nvec + npairs) * dim, batch * npairs * dim),
+                _lib.load().ctr_pairprod_fwd, emb.data_ptr(), _ld(emb), batch, nvec, dim, out.data_ptr(), _ld(out),
+                _lib.stream_ptr())
+    _lib.check(rc, "ctr_pairprod_fwd")
+    return out
+
+
+def pairprod_bwd(emb, nvec, dim, gp, attn, gpool, gemb, accumulate: bool) -> None:
+    emb, gp, gemb = _mat(emb, "emb"), _mat(gp, "gp"), _mat(gemb, "gemb")
+    if gpool is not None:
+        gpool = _mat(gpool, "gpool")
+    batch, npairs = emb.shape[0], nvec * (nvec - 1) // 2
+    rc = _timed("pairprod_bwd", lambda: (4 * batch * (2 * nvec + npairs + 1) * dim, 4 * batch * npairs * dim),
+                _lib.load().ctr_pairprod_bwd, emb.data_ptr(), _ld(emb), batch, nvec, dim, gp.data_ptr(), _ld(gp),
+                _lib.ptr(attn), _lib.ptr(gpool), _ld(gpool) if gpool is not None else 0, gemb.data_ptr(), _ld(gemb),
+                int(accumulate), _lib.stream_ptr())
+    _lib.check(rc, "ctr_pairprod_bwd")
+
+
 def cross_fwd(x0, u, xl, bias, out) -> torch.Tensor:
     """Deep & Cross combine: out = x0 * u + bias + xl"""
     x0, u, xl, out = _mat(x0, "x0"), _mat(u, "u"), _mat(xl, "xl"), _mat(out, "out")

@@ -154,6 +154,17 @@ int ctr_biinteract_fwd(const float* emb, int64_t lde, int64_t batch, int nvec, i
 int ctr_biinteract_bwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim,
                        const float* gout, int64_t ldgo, float* gemb, int64_t ldg, int accumulate, void* stream);
 
+/* AFM pair products (model/afm.py:56-60): out[(b*np + idx(i,j))*ldo + e] = v_i[e] * v_j[e], i<j
+ * lexicographic, np = nvec*(nvec-1)/2 rows per sample, nvec <= 16.
+ * bwd: gpair = gp (+ attn[b*np + p] * gpool[b] when both are given: the attention-weighted sum
+ * of afm.py:65); gemb[b,i,e] (= or +=) sum_{j!=i} gpair[b, idx(i,j), e] * v_j[e]. */
+int ctr_pairprod_fwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim,
+                     float* out, int64_t ldo, void* stream);
+int ctr_pairprod_bwd(const float* emb, int64_t lde, int64_t batch, int nvec, int dim,
+                     const float* gp, int64_t ldgp, const float* attn /*nullable*/,
+                     const float* gpool /*nullable*/, int64_t ldgo,
+                     float* gemb, int64_t ldg, int accumulate, void* stream);
+
 /* DeepFM wide part + FM second order (model/deepfm.py:63,71-77):
  *   out[b*ldo] = user1[u] + item1[i] + (x[b, dense_col0..+ndense) . wide_w + wide_b)
  *               + 0.5 * sum_e[(sum_f v_fe)^2 - sum_f v_fe^2]

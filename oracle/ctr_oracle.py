@@ -271,6 +271,28 @@ def nfm_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
     return torch.sigmoid(_lin(p, "output", torch.cat([wide, deep], dim=1)))
 
 
+def afm_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
+    """model/afm.py:41-71: vectors [user, item, age broadcast to E (:54), gender, occupation, movie];
+    the 15 element products stacked (B,15,E) (:56-60); scores = relu(P W + b) h (:63-64), softmax over
+    the pairs, weighted sum (:65), Linear(E,1) (:66); sigmoid(linear part + cross part) -> (B,1)"""
+    e = p["user_embedding.weight"].shape[1]
+    f = [
+        _emb(p, "user_embedding", ids_from_float(x[:, COL_USER])),
+        _emb(p, "item_embedding", ids_from_float(x[:, COL_ITEM])),
+        x[:, COL_AGE].unsqueeze(1).expand(-1, e),
+        bag_pool(x[:, SL_GENDER], p["gender_embedding.weight"]),
+        bag_pool(x[:, SL_OCC], p["occupation_embedding.weight"]),
+        bag_pool(x[:, SL_GENRE], p["movie_embedding.weight"]),
+    ]
+    pairs = torch.stack([f[i] * f[j] for i in range(6) for j in range(i + 1, 6)], dim=1)   # (B,15,E)
+    scores = torch.relu(torch.matmul(pairs, p["attention_W"]) + p["attention_b"])
+    weights = torch.softmax(torch.matmul(scores, p["attention_h"]), dim=1)
+    pooled = torch.sum(weights * pairs, dim=1)
+    uid, iid = ids_from_float(x[:, COL_USER]), ids_from_float(x[:, COL_ITEM])
+    linear = _emb(p, "user", uid) + _emb(p, "item", iid) + _lin(p, "linear", x[:, 2:])
+    return torch.sigmoid(linear + _lin(p, "output_layer", pooled))
+
+
 def lr_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
     """model/lr.py:24-25: sigmoid(user(u) + item(i) + Linear(43,1)(x[:,2:])) -> (B,1)"""
     uid, iid = ids_from_float(x[:, COL_USER]), ids_from_float(x[:, COL_ITEM])
@@ -369,7 +391,7 @@ def bce_loss(prob: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
 FORWARDS: Dict[str, Callable[..., torch.Tensor]] = {
     "mf": mf_forward, "neuralcf": neuralcf_forward, "ffm": ffm_forward, "pnn": pnn_forward,
     "deepcrossing": deepcrossing_forward, "deepfm": deepfm_forward, "din": din_forward,
-    "dien": dien_forward, "deepcross": deepcross_forward, "widedeep": widedeep_forward, "lr": lr_forward, "nfm": nfm_forward,
+    "dien": dien_forward, "deepcross": deepcross_forward, "widedeep": widedeep_forward, "lr": lr_forward, "nfm": nfm_forward, "afm": afm_forward,
 }
 
 

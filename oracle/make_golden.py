@@ -42,9 +42,10 @@ def _ref_classes():
     from model.widedeep import WideDeep
     from model.lr import LogisticRegression
     from model.nfm import NFM
+    from model.afm import AFM
     return dict(mf=MatrixFactorization, neuralcf=NeuralCF, ffm=FFM, pnn=PNN,
                 deepcrossing=DeepCrossing, deepfm=DeepFM, din=DIN, dien=DIEN,
-                deepcross=DeepCross, widedeep=WideDeep, lr=LogisticRegression, nfm=NFM)
+                deepcross=DeepCross, widedeep=WideDeep, lr=LogisticRegression, nfm=NFM, afm=AFM)
 
 
 # name -> (model key, ctor args, ctor kwargs, input builder(gen) -> (inputs, y))
@@ -103,6 +104,9 @@ def _cases():
     for s in (0, 1):
         c[f"nfm_s{s}"] = ("nfm", (30, 40, [32, 16, 1], 8), {}, feats(64, 30, 40, 4), s)
     c["nfm_b37"] = ("nfm", (5, 7, [16, 1], 4), {}, feats(37, 5, 7), 2)
+    for s in (0, 1):
+        c[f"afm_s{s}"] = ("afm", (30, 40, 8, 4), {}, feats(64, 30, 40, 4), s)
+    c["afm_b37"] = ("afm", (5, 7, 4, 8), {}, feats(37, 5, 7), 2)
     return c
 
 

@@ -410,6 +410,28 @@ def test_bi_interaction_pooling(ops, batch, nvec, dim):
     torch.testing.assert_close(gemb.cpu(), 2 * leaf.grad.float(), rtol=1e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("batch,nvec,dim", [(500, 6, 8), (33, 6, 128), (7, 3, 5), (2048, 4, 16)])
+def test_pair_products(ops, batch, nvec, dim):
+    # model/afm.py:56-65: the stacked pair products, and their backward incl. the attention-weighted sum
+    g = torch.Generator().manual_seed(batch * 3 + nvec + dim)
+    npairs = nvec * (nvec - 1) // 2
+    emb = torch.randn(batch, nvec * dim, generator=g)
+    out = torch.empty(batch * npairs, dim, device=DEV)
+    ops.pairprod_fwd(emb.to(DEV), nvec, dim, out)
+    leaf = emb.double().requires_grad_(True)
+    v = leaf.view(batch, nvec, dim)
+    ref = torch.stack([v[:, i] * v[:, j] for i in range(nvec) for j in range(i + 1, nvec)], dim=1)
+    assert torch.equal(out.cpu().view(batch, npairs, dim), ref.float())     # single products: exact
+    gp = torch.randn(batch, npairs, dim, generator=g)
+    attn = torch.rand(batch, npairs, generator=g)
+    gpool = torch.randn(batch, dim, generator=g)
+    ((ref * gp.double()).sum() + ((ref * attn.double().unsqueeze(-1)).sum(1) * gpool.double()).sum()).backward()
+    gemb = torch.empty(batch, nvec * dim, device=DEV)
+    ops.pairprod_bwd(emb.to(DEV), nvec, dim, gp.view(batch * npairs, dim).to(DEV), attn.to(DEV), gpool.to(DEV), gemb,
+                     accumulate=False)
+    torch.testing.assert_close(gemb.cpu(), leaf.grad.float(), rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("m,d", [(1000, 41), (257, 64), (3, 5), (4096, 641)])
 def test_cross_layer_combine(ops, m, d):
     # model/deepcross.py:14-17: x_{l+1} = x0 * u + b + x_l and its backward pieces
