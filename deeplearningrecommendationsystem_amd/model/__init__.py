@@ -15,5 +15,6 @@ from .widedeep import WideDeep
 from .lr import LogisticRegression
 from .nfm import NFM
 from .afm import AFM
+from .autorec import AutoRec
 
-__all__ = ["MatrixFactorization", "NeuralCF", "DeepFM", "PNN", "FFM", "DeepCrossing", "DIN", "DIEN", "EmbeddingStage", "DeepCross", "WideDeep", "LogisticRegression", "NFM", "AFM"]
+__all__ = ["MatrixFactorization", "NeuralCF", "DeepFM", "PNN", "FFM", "DeepCrossing", "DIN", "DIEN", "EmbeddingStage", "DeepCross", "WideDeep", "LogisticRegression", "NFM", "AFM", "AutoRec"]

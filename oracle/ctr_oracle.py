@@ -293,6 +293,11 @@ def afm_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
     return torch.sigmoid(linear + _lin(p, "output_layer", pooled))
 
 
+def autorec_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
+    """model/autorec.py:11-14: sigmoid(decoder(sigmoid(encoder(x)))) on rows of the rating matrix"""
+    return torch.sigmoid(_lin(p, "decoder", torch.sigmoid(_lin(p, "encoder", x))))
+
+
 def lr_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
     """model/lr.py:24-25: sigmoid(user(u) + item(i) + Linear(43,1)(x[:,2:])) -> (B,1)"""
     uid, iid = ids_from_float(x[:, COL_USER]), ids_from_float(x[:, COL_ITEM])
@@ -391,7 +396,7 @@ def bce_loss(prob: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
 FORWARDS: Dict[str, Callable[..., torch.Tensor]] = {
     "mf": mf_forward, "neuralcf": neuralcf_forward, "ffm": ffm_forward, "pnn": pnn_forward,
     "deepcrossing": deepcrossing_forward, "deepfm": deepfm_forward, "din": din_forward,
-    "dien": dien_forward, "deepcross": deepcross_forward, "widedeep": widedeep_forward, "lr": lr_forward, "nfm": nfm_forward, "afm": afm_forward,
+    "dien": dien_forward, "deepcross": deepcross_forward, "widedeep": widedeep_forward, "lr": lr_forward, "nfm": nfm_forward, "afm": afm_forward, "autorec": autorec_forward,
 }
 
 

@@ -43,9 +43,10 @@ def _ref_classes():
     from model.lr import LogisticRegression
     from model.nfm import NFM
     from model.afm import AFM
+    from model.autorec import AutoRec
     return dict(mf=MatrixFactorization, neuralcf=NeuralCF, ffm=FFM, pnn=PNN,
                 deepcrossing=DeepCrossing, deepfm=DeepFM, din=DIN, dien=DIEN,
-                deepcross=DeepCross, widedeep=WideDeep, lr=LogisticRegression, nfm=NFM, afm=AFM)
+                deepcross=DeepCross, widedeep=WideDeep, lr=LogisticRegression, nfm=NFM, afm=AFM, autorec=AutoRec)
 
 
 # name -> (model key, ctor args, ctor kwargs, input builder(gen) -> (inputs, y))
@@ -107,6 +108,16 @@ def _cases():
     for s in (0, 1):
         c[f"afm_s{s}"] = ("afm", (30, 40, 8, 4), {}, feats(64, 30, 40, 4), s)
     c["afm_b37"] = ("afm", (5, 7, 4, 8), {}, feats(37, 5, 7), 2)
+
+    def ratings(rows, cols):
+        # rows of a rating matrix as scripts/autorec.py builds it: 1 liked, 0 disliked, 0.5 unknown
+        def f(g):
+            x = torch.randint(0, 3, (rows, cols), generator=g).float() * 0.5
+            return [x], (torch.rand(rows, cols, generator=g) < 0.5).float()
+        return f
+
+    c["autorec_s0"] = ("autorec", (50, 16), {}, ratings(64, 50), 0)
+    c["autorec_b37"] = ("autorec", (21, 8), {}, ratings(37, 21), 2)
     return c
 
 

@@ -24,7 +24,7 @@ def _models():
     return {name: getattr(model, cls) for name, cls in
             dict(mf="MatrixFactorization", neuralcf="NeuralCF", ffm="FFM", pnn="PNN",
                  deepcrossing="DeepCrossing", deepfm="DeepFM", din="DIN", dien="DIEN", deepcross="DeepCross",
-                 widedeep="WideDeep", lr="LogisticRegression", nfm="NFM", afm="AFM").items()
+                 widedeep="WideDeep", lr="LogisticRegression", nfm="NFM", afm="AFM", autorec="AutoRec").items()
             if hasattr(model, cls)}
 
 
