@@ -110,13 +110,15 @@ class NeuralCF(CtrModule):
         self._raise_if_bad_index()
         return out
 
-    def recommendation(self, num_users, num_items):
-        """score every (user, item) pair and rank (reference model/neuralcf.py:61-72)"""
-        rows = []
+    def recommendation(self, num_users, num_items, chunk: int = 1 << 20):
+        """score every (user, item) pair and rank: the result of the reference's per-user loop
+        (model/neuralcf.py:61-72; 943 forward calls of 1682 samples) from a few forward calls over
+        the whole user x item grid, ``chunk`` pairs at a time, ranked on the device"""
         dev = self.GMF_Embedding_User.weight.device
-        items = torch.arange(num_items, device=dev)
+        users = torch.arange(num_users, device=dev).repeat_interleave(num_items)
+        items = torch.arange(num_items, device=dev).repeat(num_users)
+        scores = torch.empty(num_users * num_items, dtype=torch.float32, device=dev)
         with torch.no_grad():
-            for u in range(num_users):
-                scores = self.forward(torch.full((num_items,), u, device=dev), items)
-                rows.append(torch.topk(scores, num_items, dim=0).indices.view(-1).tolist())
-        return np.array(rows)
+            for lo in range(0, users.numel(), chunk):
+                scores[lo:lo + chunk] = self.forward(users[lo:lo + chunk], items[lo:lo + chunk]).view(-1)
+        return torch.topk(scores.view(num_users, num_items), num_items, dim=1).indices.cpu().numpy()

@@ -362,6 +362,22 @@ def test_row_sharded_item_table_two_ranks_match_the_unsharded_model(kind):
     assert results == {0: "ok", 1: "ok"}, results
 
 
+def test_neuralcf_recommendation_over_the_whole_grid_matches_the_per_user_loop():
+    # the reference ranks user by user (model/neuralcf.py:61-72); the mirror scores
+    # the user x item grid in a few launches -- same ranking
+    from deeplearningrecommendationsystem_amd.model import NeuralCF
+    torch.manual_seed(8)
+    nu, ni = 23, 31
+    model = NeuralCF(nu, ni, 8, [16, 8, 4]).to(DEV)
+    got = model.recommendation(nu, ni, chunk=200)            # several chunks, last one ragged
+    items = torch.arange(ni, device=DEV)
+    with torch.no_grad():
+        for u in range(nu):
+            scores = model(torch.full((ni,), u, device=DEV), items).view(-1)
+            want = torch.topk(scores, ni).indices.cpu().numpy()
+            assert (got[u] == want).all() or torch.equal(scores[got[u]], scores[want])   # ties may swap
+
+
 def test_trainer_mirror_trains_neuralcf_eager_and_graphed():
     # Trainer call convention of trainer/trainer.py:23-78 on the HIP module; the graphed
     # step must produce the same parameter updates as the eager one
