@@ -64,6 +64,7 @@ struct StackDesc {
 // BASELINE NeuralCF tower): the layer loops unroll, the index divisions, tail chunks and
 // range guards fold away -- the generic kernel spends ~3x its MFMA time issuing them.
 struct DynShape {
+  static constexpr int kWavesPerSimd = 1;
   static constexpr bool kFixed = false;
   static constexpr int kLayers = 0;
   static constexpr int N[1] = {0};
@@ -71,6 +72,7 @@ struct DynShape {
   static constexpr int ACT[1] = {0};
 };
 struct NcfShape {  // model/neuralcf.py:23-27 at BASELINE configs[1]: 128 -> 64 -> 32 -> 16 -> 8 -> 64
+  static constexpr int kWavesPerSimd = 1;  // 224 dW accumulator registers: one wave per SIMD
   static constexpr bool kFixed = true;
   static constexpr int kLayers = 5;
   static constexpr int N[5] = {64, 32, 16, 8, 64};
@@ -78,6 +80,7 @@ struct NcfShape {  // model/neuralcf.py:23-27 at BASELINE configs[1]: 128 -> 64 
   static constexpr int ACT[5] = {CTR_ACT_RELU, CTR_ACT_RELU, CTR_ACT_RELU, CTR_ACT_RELU, CTR_ACT_NONE};
 };
 struct DienAttShape {  // model/dien.py:13-19 at BASELINE configs[4] (E = 16) on the folded [h, t] operand: 32 -> 64 -> 32 -> 1
+  static constexpr int kWavesPerSimd = 2;  // small stack: <=256 registers and <=80 KB of LDS, two workgroups per CU
   static constexpr bool kFixed = true;
   static constexpr int kLayers = 3;
   static constexpr int N[3] = {64, 32, 1};
@@ -343,7 +346,7 @@ __device__ __forceinline__ void fwd_chunk(const float* xt, int xstride, const fl
 }
 
 template <class S>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads, S::kWavesPerSimd)
 mlp_fwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int64_t m) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // layer descriptors are read inside the per-tile layer loop: from LDS, not from the
@@ -475,7 +478,7 @@ __device__ __forceinline__ void dx_chunk(const float* gt, int gstride, const flo
 }
 
 template <class S, int MAXT>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads, S::kWavesPerSimd)
 mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int64_t m, const float* __restrict__ gy,
                int64_t ldgy, float* __restrict__ gx, int64_t ldgx, float* __restrict__ ws, int64_t slab) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -940,6 +943,10 @@ extern "C" int ctr_mlp_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp
   } else if (matches<DienAttShape, false>(layers, nlayers, b.d)) {
     rc = allow_lds(mlp_fwd_kernel<DienAttShape>, b.lds_bytes);
     if (rc != CTR_OK) return rc;
+    if (2 * b.lds_bytes <= 160 * 1024) {  // two resident workgroups per CU: twice the waves to hide latency
+      grid = ctr_ceil_div(tiles, kWaves);
+      if (grid > 512) grid = 512;
+    }
     hipLaunchKernelGGL(mlp_fwd_kernel<DienAttShape>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes,
                        (hipStream_t)stream, b.d, x, ldx, m);
   } else {
@@ -977,7 +984,14 @@ extern "C" int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp
                        m, gy, ldgy, gx, ldgx, workspace, b.slab);                                                  \
   } while (0)
   if (matches<NcfShape, true>(layers, nlayers, b.d)) CTR_LAUNCH_BWD(NcfShape, 14);
-  else if (matches<DienAttShape, true>(layers, nlayers, b.d)) CTR_LAUNCH_BWD(DienAttShape, 8);
+  else if (matches<DienAttShape, true>(layers, nlayers, b.d)) {
+    if (2 * b.lds_bytes <= 160 * 1024) {  // two resident workgroups per CU (the kernel is capped at 256 registers)
+      grid = ctr_ceil_div(tiles, kWaves);
+      if (grid > 512) grid = 512;
+      CTR_REQUIRE(workspace_floats >= grid * b.slab, CTR_ELIMIT);
+    }
+    CTR_LAUNCH_BWD(DienAttShape, 6);
+  }
   else if (maxt == 8) CTR_LAUNCH_BWD(DynShape, 8);
   else if (maxt == 12) CTR_LAUNCH_BWD(DynShape, 12);
   else if (maxt == 14) CTR_LAUNCH_BWD(DynShape, 14);
