@@ -27,9 +27,10 @@ constexpr int kBM = 128;
 constexpr int kBK = 16;             // contraction depth of one pipeline step
 constexpr int kHalf = kBK / 2;      // values per lane and step: the lane halves take kk = kHalf*h + t
 constexpr int kKcStride = kBK + 4;  // floats; 80 B rows: 8 consecutive rows cover all 32 banks with b128 reads
-// resident workgroups per CU = waves per SIMD.  Forward (both operands KC): 41 KB of LDS -> 3;
-// dX / dW stage one or both operands [kk][row] (34-37 KB) and fit 4 with <= 128 VGPRs
-constexpr int wg_per_cu(int amode, int bmode) { return (amode == 0 && bmode == 0) ? 3 : 4; }
+// resident workgroups per CU = waves per SIMD: four.  The forward (both operands KC) needs exactly
+// 4 x 40960 B = the CU's 160 KB of LDS and fits the 128-register cap without a spill; dX / dW
+// stage one or both operands [kk][row] (34-37 KB)
+constexpr int wg_per_cu(int, int) { return 4; }
 
 enum { KC = 0, KS = 1 };
 

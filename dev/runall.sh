@@ -1,7 +1,7 @@
-for w in ; do
+for w in deepfm pnn deepcrossing deepcross widedeep nfm; do
   python bench.py --workload $w --steps 30 --warmup 5 > gpurun_out/bench_$w.json 2>gpurun_out/bench_$w.err || { echo FAIL $w; tail -5 gpurun_out/bench_$w.err; }
 done
-for w in dien; do
+for w in din; do
   python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_$w.json 2>gpurun_out/bench_$w.err || { echo FAIL $w; tail -5 gpurun_out/bench_$w.err; }
 done
 python - <<'PY'
