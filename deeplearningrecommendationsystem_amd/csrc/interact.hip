@@ -219,12 +219,19 @@ fm_wide_bwd_kernel(const Geometry g, const float* __restrict__ emb, int64_t lde,
   extern __shared__ float lds[];
   __shared__ float s_w[kMaxDense + 1];  // block-level sums for w and b
   float* s_g = lds + g.tb * g.row;      // [tb]
+  float* s_x = s_g + g.tb;              // [tb][ndense]: the dense feature columns of the tile
   const int chunks = g.e / VEC;
   for (int i = threadIdx.x; i <= a.ndense; i += blockDim.x) s_w[i] = 0.0f;
   for (int64_t b0 = (int64_t)blockIdx.x * g.tb; b0 < batch; b0 += (int64_t)gridDim.x * g.tb) {
     const int count = (int)(batch - b0 < g.tb ? batch - b0 : g.tb);
     stage_vectors<VEC>(lds, g, emb, lde, b0, count);
     for (int s = threadIdx.x; s < count; s += blockDim.x) s_g[s] = gout[(b0 + s) * ldgo];
+    // all 256 threads fetch the tile's dense columns (coalesced): the weight-gradient loop below
+    // used to read them from HBM with 44 threads, one dependent load per sample
+    for (int i = threadIdx.x; i < count * a.ndense; i += blockDim.x) {
+      const int s = i / a.ndense, c = i - s * a.ndense;
+      s_x[i] = a.x[(b0 + s) * a.ldx + a.dense_col0 + c];
+    }
     __syncthreads();
     // per-sample scalars: id tables
     for (int s = threadIdx.x; s < count; s += blockDim.x) {
@@ -241,7 +248,7 @@ fm_wide_bwd_kernel(const Geometry g, const float* __restrict__ emb, int64_t lde,
       for (int c = threadIdx.x; c <= a.ndense; c += blockDim.x) {
         float acc = 0.0f;
         for (int s = 0; s < count; ++s) {
-          const float xv = c < a.ndense ? a.x[(b0 + s) * a.ldx + a.dense_col0 + c] : 1.0f;
+          const float xv = c < a.ndense ? s_x[s * a.ndense + c] : 1.0f;
           acc = fmaf(s_g[s], xv, acc);
         }
         s_w[c] += acc;
@@ -335,6 +342,7 @@ ffm_head_bwd_kernel(const Geometry g, const float* __restrict__ emb, int64_t lde
   float* s_dot = lds + g.tb * g.row;      // [tb][npairs] then reused
   float* s_dz = s_dot + g.tb * pl.n;      // [tb] dlogit
   float* s_cross = s_dz + g.tb;           // [tb]
+  float* s_x = s_cross + g.tb;            // [tb][ndense]: the dense feature columns of the tile
   const int chunks = g.e / VEC;
   for (int i = threadIdx.x; i <= a.ndense; i += blockDim.x) s_w[i] = 0.0f;
   if (threadIdx.x == 0) {
@@ -345,6 +353,10 @@ ffm_head_bwd_kernel(const Geometry g, const float* __restrict__ emb, int64_t lde
   for (int64_t b0 = (int64_t)blockIdx.x * g.tb; b0 < batch; b0 += (int64_t)gridDim.x * g.tb) {
     const int count = (int)(batch - b0 < g.tb ? batch - b0 : g.tb);
     stage_vectors<VEC>(lds, g, emb, lde, b0, count);
+    for (int i = threadIdx.x; i < count * a.ndense; i += blockDim.x) {  // see fm_wide_bwd_kernel
+      const int s = i / a.ndense, c = i - s * a.ndense;
+      s_x[i] = a.x[(b0 + s) * a.ldx + a.dense_col0 + c];
+    }
     __syncthreads();
     for (int w = threadIdx.x; w < count * pl.n; w += blockDim.x) {
       const int s = w / pl.n, p = w - s * pl.n;
@@ -371,7 +383,7 @@ ffm_head_bwd_kernel(const Geometry g, const float* __restrict__ emb, int64_t lde
       for (int c = threadIdx.x; c <= a.ndense; c += blockDim.x) {
         float acc = 0.0f;
         for (int s = 0; s < count; ++s) {
-          const float xv = c < a.ndense ? a.x[(b0 + s) * a.ldx + a.dense_col0 + c] + s_cross[s] : 1.0f;
+          const float xv = c < a.ndense ? s_x[s * a.ndense + c] + s_cross[s] : 1.0f;
           acc = fmaf(s_dz[s], xv, acc);
         }
         s_w[c] += acc;
@@ -550,9 +562,9 @@ extern "C" int ctr_fm_wide_bwd(const float* emb, int64_t lde, int64_t batch, int
                                wide_w, wide_b);
   int rc = check_wide(a);
   if (rc != CTR_OK) return rc;
-  const Geometry g = make_geometry(nvec, dim, ctr_aligned16(emb) && lde % 4 == 0, 1);
+  const Geometry g = make_geometry(nvec, dim, ctr_aligned16(emb) && lde % 4 == 0, 1 + ndense);
   CTR_REQUIRE(g.tb >= 1, CTR_ELIMIT);
-  const size_t dyn = (size_t)g.tb * (g.row + 1) * sizeof(float);
+  const size_t dyn = (size_t)g.tb * (g.row + 1 + ndense) * sizeof(float);
   const WideGrads wg{guser1, gitem1, gwide_w, gwide_b};
   int grid = tile_grid(batch, g.tb);
   float* ws = small_grad_workspace(workspace, workspace_floats, ndense, gwide_w || gwide_b, &grid);
@@ -636,9 +648,9 @@ extern "C" int ctr_ffm_head_bwd(const float* emb, int64_t lde, int64_t batch, in
                                lin_w, lin_b);
   rc = check_wide(a);
   if (rc != CTR_OK) return rc;
-  const Geometry g = make_geometry(nvec, dim, ctr_aligned16(emb) && lde % 4 == 0, npairs + 2);
+  const Geometry g = make_geometry(nvec, dim, ctr_aligned16(emb) && lde % 4 == 0, npairs + 2 + ndense);
   CTR_REQUIRE(g.tb >= 1, CTR_ELIMIT);
-  const size_t dyn = (size_t)g.tb * (g.row + npairs + 2) * sizeof(float);
+  const size_t dyn = (size_t)g.tb * (g.row + npairs + 2 + ndense) * sizeof(float);
   const WideGrads wg{guser1, gitem1, glin_w, glin_b};
   int grid = tile_grid(batch, g.tb);
   float* ws = small_grad_workspace(workspace, workspace_floats, ndense, glin_w || glin_b, &grid);

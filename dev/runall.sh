@@ -1,7 +1,7 @@
-for w in deepfm pnn deepcrossing deepcross widedeep nfm; do
+for w in ffm deepfm lr widedeep; do
   python bench.py --workload $w --steps 30 --warmup 5 > gpurun_out/bench_$w.json 2>gpurun_out/bench_$w.err || { echo FAIL $w; tail -5 gpurun_out/bench_$w.err; }
 done
-for w in din; do
+for w in ; do
   python bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_$w.json 2>gpurun_out/bench_$w.err || { echo FAIL $w; tail -5 gpurun_out/bench_$w.err; }
 done
 python - <<'PY'
