@@ -1,0 +1,229 @@
+// Forward GEMM  Y = act(X W^T + b (+R))  with operands streamed global -> LDS directly
+// (global_load_lds_dwordx4, gfx950): no staging registers, no ds_write, and a THREE-stage LDS
+// ring, so the loads of pipeline slot g+2 are issued at step g and have two steps to land
+// (the register-staged tile kernel of linear.hip has one; PMC: 43 % of its wave time in vmcnt).
+//
+// Tile 128 x (32*NT) per 256-thread workgroup, 16-deep steps, persistent over the M tiles like
+// linear.hip.  A direct load writes lane L's 16 bytes at M0 + 16*L: the LDS image of a wave's
+// instruction is one contiguous 1 KB run and cannot be padded, so bank conflicts are avoided by
+// choosing WHICH global chunk each lane fetches: slot q of a stage (16 B each, row = q/4) holds
+// k-chunk (q & 3) ^ ((row >> 1) & 3) of its row -- the 8 rows a quarter-wave reads with one
+// ds_read_b128 then cover all 32 banks.
+// Requirements (else ctr_linear_fwd keeps the tile kernel): K % 16 == 0, X / W rows 16-byte
+// aligned (ld % 4 == 0).  Rows past M / N are clamped to the last row: their products are
+// computed and dropped.
+#include "ctr_common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+constexpr int kBM = 128;
+constexpr int kBK = 16;
+constexpr int kStages = 3;
+
+struct DldsArgs {
+  const float* x; int64_t ldx;
+  const float* w; int64_t ldw;
+  const float* bias;
+  const float* res; int64_t ldr;
+  float* y; int64_t ldy;
+  int64_t m; int n; int64_t k; int act;
+};
+
+// s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));
+}
+
+// fetch one operand tile (ROWS x 16 floats) into a stage: chunk slot q = 64*wave + lane + 256*i
+template <int ROWS>
+__device__ __forceinline__ void fetch(float* stage, const float* __restrict__ src, int64_t ld, int64_t row0,
+                                      int64_t rows_total, int64_t k0, int lane, int wave) {
+  constexpr int kChunks = ROWS * 4;
+  constexpr int kIters = (kChunks + kThreads - 1) / kThreads;
+#pragma unroll
+  for (int i = 0; i < kIters; ++i) {
+    // first slot of this wave's instruction (uniform).  A tile of fewer chunks than threads is fetched twice
+    // (same bytes to the same slots): every wave then has the same number of loads in flight, which
+    // the vmcnt bookkeeping of the ring relies on
+    int q0 = 64 * wave + kThreads * i;
+    if (kChunks % kThreads != 0 && q0 >= kChunks) q0 -= kChunks;
+    const int q = q0 + lane;
+    const int row = q >> 2, c = (q & 3) ^ ((row >> 1) & 3);
+    int64_t gr = row0 + row;
+    gr = gr < rows_total ? gr : rows_total - 1;
+    const float* g = src + gr * ld + k0 + c * 4;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(stage + q0 * 4), 16, 0, 0);
+  }
+}
+
+// The operand fragments are read with ds_read_b128 written as asm: the compiler cannot tell which
+// stage an LDS-DMA load targets and would put s_waitcnt vmcnt(0) in front of every ordinary LDS read --
+// waiting for the loads issued a moment ago, i.e. no pipeline at all.  The waits are placed by hand
+// (wait_vmcnt before the barrier, lds_fence after the reads).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 lds_read128(uint32_t byte_addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
+  return v;
+}
+__device__ __forceinline__ uint32_t lds_addr(const float* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+}
+// byte offset inside a stage of the two 16-byte chunks (kk = 8h .. 8h+3, 8h+4 .. 8h+7) of tile row `row`
+__device__ __forceinline__ void frag_offsets(int row, int h, uint32_t (&off)[2]) {
+  const int sw = (row >> 1) & 3;
+#pragma unroll
+  for (int v = 0; v < 2; ++v) off[v] = (uint32_t)(row * 4 + ((2 * h + v) ^ sw)) * 16u;
+}
+
+template <int NT>
+__global__ void __launch_bounds__(kThreads, 3)
+gemm_fwd_dlds_kernel(const DldsArgs a) {
+  constexpr int BN = 32 * NT;
+  constexpr int kLoadsA = kBM * 4 / kThreads;                      // 2
+  constexpr int kLoadsB = (BN * 4 + kThreads - 1) / kThreads;      // NT=4: 2, NT=2: 1, NT=1: 1 (half the waves)
+  constexpr int kPerSlot = kLoadsA + kLoadsB;
+  __shared__ __attribute__((aligned(16))) float s_a[kStages][kBM * kBK];
+  __shared__ __attribute__((aligned(16))) float s_b[kStages][BN * kBK];
+
+  const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t mtiles = (a.m + kBM - 1) / kBM;
+  const int64_t j0 = (int64_t)blockIdx.y * BN;
+  const int nk = (int)(a.k / kBK);
+  int64_t tile = blockIdx.x;
+  if (tile >= mtiles) return;
+
+  constexpr int CH = 4 / NT;
+  floatx16 acc[NT][CH];
+  // the workgroup's bias columns, fetched once: a load inside the tile loop's epilogue would have to
+  // drain the in-order vmcnt queue, i.e. wait for the operand loads of the next tile
+  float bj[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int64_t j = j0 + 32 * n + (lane0 & 31);
+    bj[n] = a.bias && j < a.n ? a.bias[j] : 0.0f;
+  }
+  wait_vmcnt<0>();  // ... and landed before the ring starts, so that no later use of bj waits on the queue
+
+  auto advance = [&](int64_t& t, int& k) {
+    if (++k == nk) {
+      k = 0;
+      t += gridDim.x;
+    }
+  };
+  auto issue = [&](int stage, int64_t t, int k) {
+    fetch<kBM>(s_a[stage], a.x, a.ldx, t * kBM, a.m, (int64_t)k * kBK, lane0, wave);
+    fetch<BN>(s_b[stage], a.w, a.ldw, j0, a.n, (int64_t)k * kBK, lane0, wave);
+  };
+  // slots g+1 and g+2 relative to the one being multiplied
+  int64_t t1 = tile, t2;
+  int k1 = 0, k2;
+  advance(t1, k1);
+  t2 = t1;
+  k2 = k1;
+  advance(t2, k2);
+  issue(0, tile, 0);
+  if (t1 < mtiles) issue(1, t1, k1);
+  int stage = 0;
+  for (; tile < mtiles; tile += gridDim.x) {
+    const int64_t i0 = tile * kBM;
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));  // keep the epilogue's 64 addresses out of the tile loop's live set
+    const int r = lane & 31, h = lane >> 5;
+    uint32_t aoff[2], boff[2];
+    frag_offsets(32 * wave + r, h, aoff);
+    frag_offsets(r, h, boff);  // rows 32n + r: same swizzle for every n (32n >> 1 is a multiple of 4)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[n][c][e] = 0.0f;
+    for (int ks = 0; ks < nk; ++ks) {
+      // my loads of the slot to multiply have landed (only those of the next slot may be in flight),
+      // then everybody's have, and everybody is done reading the stage that is refilled next
+      if (t1 < mtiles) wait_vmcnt<kPerSlot>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      int refill = stage + 2;
+      refill = refill >= kStages ? refill - kStages : refill;
+      f32x4 fa[2], fb[NT][2];
+      const uint32_t abase = lds_addr(s_a[0]) + (uint32_t)stage * (kBM * kBK * 4);
+      const uint32_t bbase = lds_addr(s_b[0]) + (uint32_t)stage * (BN * kBK * 4);
+#pragma unroll
+      for (int v = 0; v < 2; ++v) fa[v] = lds_read128(abase + aoff[v]);
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) fb[n][v] = lds_read128(bbase + boff[v] + (uint32_t)n * (32 * kBK * 4));
+      if (t2 < mtiles) issue(refill, t2, k2);
+      advance(t1, k1);
+      advance(t2, k2);
+      // every fragment register passes through the wait, so no MFMA can be scheduled above it
+      if constexpr (NT == 1)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0][0]), "+v"(fb[0][1]));
+      else if constexpr (NT == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]),
+                       "+v"(fb[2][0]), "+v"(fb[2][1]), "+v"(fb[3][0]), "+v"(fb[3][1]));
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[n][t % CH] =
+              __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t >> 2][t & 3], fb[n][t >> 2][t & 3], acc[n][t % CH], 0, 0, 0);
+      stage = stage + 1 == kStages ? 0 : stage + 1;
+    }
+    // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int64_t j = j0 + 32 * n + r;
+      if (j < a.n) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t i = i0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h;
+          float v = acc[n][0][e];
+#pragma unroll
+          for (int c = 1; c < CH; ++c) v += acc[n][c][e];
+          if (i < a.m) {
+            float z = v + bj[n];
+            if (a.res) z += a.res[i * a.ldr + j];
+            a.y[i * a.ldy + j] = ctr_act(z, a.act);
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool ctr_gemm_dlds_ok(const float* x, int64_t ldx, const float* w, int64_t ldw, int64_t m, int n, int k) {
+  return k % kBK == 0 && k >= kBK && m >= 1 && n >= 1 && ctr_aligned16(x) && ctr_aligned16(w) && ldx % 4 == 0 &&
+         ldw % 4 == 0;
+}
+
+int ctr_gemm_dlds_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* res,
+                      int64_t ldr, float* y, int64_t ldy, int64_t m, int n, int k, int act, hipStream_t st) {
+  const int nt = n <= 32 ? 1 : (n <= 64 ? 2 : 4);
+  const int64_t mtiles = ctr_ceil_div(m, kBM);
+  const int64_t ny = ctr_ceil_div(n, 32 * nt);
+  int64_t gx = ctr_ceil_div(256 * 3, ny);
+  if (gx > mtiles) gx = mtiles;
+  if (gx < 1) gx = 1;
+  CTR_REQUIRE(ny <= 65535, CTR_ELIMIT);
+  const DldsArgs a{x, ldx, w, ldw, bias, res, ldr, y, ldy, m, n, (int64_t)k, act};
+  const dim3 grid((unsigned)gx, (unsigned)ny);
+  if (nt == 1) hipLaunchKernelGGL(gemm_fwd_dlds_kernel<1>, grid, dim3(kThreads), 0, st, a);
+  else if (nt == 2) hipLaunchKernelGGL(gemm_fwd_dlds_kernel<2>, grid, dim3(kThreads), 0, st, a);
+  else hipLaunchKernelGGL(gemm_fwd_dlds_kernel<4>, grid, dim3(kThreads), 0, st, a);
+  return ctr_launch_status();
+}
