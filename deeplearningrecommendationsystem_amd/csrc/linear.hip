@@ -477,6 +477,17 @@ extern "C" int ctr_linear_bwd(const float* x, int64_t ldx, const float* w, int64
     gw = nullptr;
     gb = nullptr;
   }
+  // wide layers with aligned operands: gY, Y and X stream global -> LDS directly (gemm_dlds_dw.hip)
+  if (gw && workspace && ctr_gemm_dlds_dw_ok(x, ldx, y, ldy, gy, ldgy, gw, ldgw, m, n, k, act)) {
+    int rc = ctr_gemm_dlds_dw(x, ldx, y, ldy, gy, ldgy, gw, gb, m, n, k, act, workspace, workspace_floats, st);
+    if (rc == CTR_OK) {
+      if (!gx) return rc;
+      gw = nullptr;
+      gb = nullptr;
+    } else if (rc != CTR_ELIMIT) {
+      return rc;
+    }
+  }
   GzSrc gz;
   gz.gy = plain(gy, ldgy, m, n);
   gz.y = plain(y ? y : gy, y ? ldy : ldgy, m, n);
