@@ -136,6 +136,11 @@ bool ctr_gemm_dlds_dw_ok(const float* x, int64_t ldx, const float* y, int64_t ld
 int ctr_gemm_dlds_dw(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gy, int64_t ldgy, float* gw,
                      float* gb, int64_t m, int n, int k, int act, float* workspace, int64_t workspace_floats,
                      hipStream_t st);
+// gemm_dlds_dx.hip: input gradient with direct global->LDS operand loads
+bool ctr_gemm_dlds_dx_ok(const float* w, int64_t ldw, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
+                         int64_t m, int n, int k, int act);
+int ctr_gemm_dlds_dx(const float* w, int64_t ldw, const float* y, int64_t ldy, const float* gy, int64_t ldgy, float* gx,
+                     int64_t ldgx, int accumulate, int64_t m, int n, int k, int act, hipStream_t st);
 int ctr_n1_fwd(const float* x, int64_t ldx, const float* w, const float* bias, const float* res, int64_t ldr, float* y,
                int64_t ldy, int64_t m, int k, int act, hipStream_t st);
 int ctr_n1_bwd(const float* x, int64_t ldx, const float* w, const float* y, int64_t ldy, const float* gy, int64_t ldgy,

@@ -1,0 +1,228 @@
+// Input gradient  gX[m, :k] (=|+=) sum_n gZ[m, n] W[n, :k],  gZ = gY * act'(Y),  with gY, Y and W copied
+// global -> LDS directly (global_load_lds_dwordx4) through a three-stage ring; see gemm_dlds.hip for the
+// ring and gemm_dlds_dw.hip for why the loads are issued from asm.
+//
+// Tile 128 rows x 32*NT input columns per 256-thread workgroup, persistent over the row tiles; a step
+// contracts 16 units.  gY / Y tiles are [128][16] with the chunk swizzle of gemm_dlds.hip (read with
+// ds_read_b128 along the units), the W tile is the plain row-major [16][32*NT] block and is read down
+// its rows (32 consecutive floats per half-wave: conflict-free).  act'(Y) is applied as gY is read.
+// Requirements (else the tile kernel of linear.hip runs): n % 16 == 0, k % 4 == 0, 16-byte aligned rows.
+#include "ctr_common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+constexpr int kBM = 128;
+constexpr int kBK = 16;
+constexpr int kStages = 3;
+
+struct DxArgs {
+  const float* gy; int64_t ldgy;
+  const float* y; int64_t ldy;
+  const float* w; int64_t ldw;
+  float* gx; int64_t ldgx;
+  int64_t m; int n; int k; int accumulate;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));
+}
+
+__device__ __forceinline__ void dma16(const float* g, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_base) : "memory");
+}
+
+__device__ __forceinline__ uint32_t lds_addr(const float* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+}
+
+// [128 rows][16 units] tile, slot q (16 B) = row q/4, unit chunk (q & 3) ^ ((row >> 1) & 3)
+__device__ __forceinline__ void fetch_rows(float* stage, const float* __restrict__ src, int64_t ld, int64_t row0,
+                                           int64_t rows_total, int u0, int lane, int wave) {
+#pragma unroll
+  for (int i = 0; i < kBM * 4 / kThreads; ++i) {
+    const int q0 = 64 * wave + kThreads * i;
+    const int q = q0 + lane;
+    const int row = q >> 2, c = (q & 3) ^ ((row >> 1) & 3);
+    int64_t gr = row0 + row;
+    gr = gr < rows_total ? gr : rows_total - 1;
+    dma16(src + gr * ld + u0 + c * 4, __builtin_amdgcn_readfirstlane(lds_addr(stage + q0 * 4)));
+  }
+}
+
+// plain [16 units][W columns] block of the weight
+template <int W>
+__device__ __forceinline__ void fetch_w(float* stage, const float* __restrict__ w, int64_t ldw, int u0, int col0,
+                                        int cols_total, int lane, int wave) {
+  constexpr int kPerRow = W / 4, kChunks = 16 * kPerRow;
+  constexpr int kIters = (kChunks + kThreads - 1) / kThreads;
+#pragma unroll
+  for (int i = 0; i < kIters; ++i) {
+    int q0 = 64 * wave + kThreads * i;
+    if (kChunks % kThreads != 0 && q0 >= kChunks) q0 -= kChunks;  // narrow tile: fetched twice, same bytes
+    const int q = q0 + lane;
+    const int row = q / kPerRow, cc = q % kPerRow;
+    int col = col0 + cc * 4;
+    col = col < cols_total ? col : 0;
+    dma16(w + (int64_t)(u0 + row) * ldw + col, __builtin_amdgcn_readfirstlane(lds_addr(stage + q0 * 4)));
+  }
+}
+
+template <int NT, int ACT>
+__global__ void __launch_bounds__(kThreads, 2)
+gemm_dx_dlds_kernel(const DxArgs a) {
+  constexpr int BW = 32 * NT;
+  constexpr bool has_y = ACT != CTR_ACT_NONE;
+  constexpr int kLoadsW = (16 * (BW / 4) + kThreads - 1) / kThreads;
+  constexpr int kPerSlot = (has_y ? 2 : 1) * (kBM * 4 / kThreads) + kLoadsW;
+  __shared__ __attribute__((aligned(16))) float s_gy[kStages][kBM * kBK];
+  __shared__ __attribute__((aligned(16))) float s_y[has_y ? kStages : 1][has_y ? kBM * kBK : 4];
+  __shared__ __attribute__((aligned(16))) float s_w[kStages][kBK * BW];
+
+  const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t mtiles = (a.m + kBM - 1) / kBM;
+  const int c0 = blockIdx.y * BW;
+  const int nk = a.n / kBK;
+  int64_t tile = blockIdx.x;
+  if (tile >= mtiles) return;
+
+  constexpr int CH = 4 / NT;
+  floatx16 acc[NT][CH];
+
+  auto advance = [&](int64_t& t, int& ks) {
+    if (++ks == nk) {
+      ks = 0;
+      t += gridDim.x;
+    }
+  };
+  auto issue = [&](int stage, int64_t t, int ks) {
+    fetch_rows(s_gy[stage], a.gy, a.ldgy, t * kBM, a.m, ks * kBK, lane0, wave);
+    if (has_y) fetch_rows(s_y[stage], a.y, a.ldy, t * kBM, a.m, ks * kBK, lane0, wave);
+    fetch_w<BW>(s_w[stage], a.w, a.ldw, ks * kBK, c0, a.k, lane0, wave);
+  };
+  int64_t t1 = tile, t2;
+  int k1 = 0, k2;
+  advance(t1, k1);
+  t2 = t1;
+  k2 = k1;
+  advance(t2, k2);
+  issue(0, tile, 0);
+  if (t1 < mtiles) issue(1, t1, k1);
+  int stage = 0;
+  for (; tile < mtiles; tile += gridDim.x) {
+    const int64_t i0 = tile * kBM;
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int r = lane & 31, h = lane >> 5;
+    const int arow = 32 * wave + r, sw = (arow >> 1) & 3;
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb)
+#pragma unroll
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nb][c][e] = 0.0f;
+    for (int ks = 0; ks < nk; ++ks) {
+      if (t1 < mtiles) wait_vmcnt<kPerSlot>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      int refill = stage + 2;
+      refill = refill >= kStages ? refill - kStages : refill;
+      if (t2 < mtiles) issue(refill, t2, k2);
+      advance(t1, k1);
+      advance(t2, k2);
+      float fa[8];
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const int slot = arow * 4 + ((2 * h + v) ^ sw);
+        const float4 g = *reinterpret_cast<const float4*>(&s_gy[stage][slot * 4]);
+        fa[4 * v + 0] = g.x; fa[4 * v + 1] = g.y; fa[4 * v + 2] = g.z; fa[4 * v + 3] = g.w;
+        if (has_y) {
+          const float4 yv = *reinterpret_cast<const float4*>(&s_y[stage][slot * 4]);
+          fa[4 * v + 0] *= ctr_act_grad(yv.x, ACT);
+          fa[4 * v + 1] *= ctr_act_grad(yv.y, ACT);
+          fa[4 * v + 2] *= ctr_act_grad(yv.z, ACT);
+          fa[4 * v + 3] *= ctr_act_grad(yv.w, ACT);
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb) {
+        float fb[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) fb[t] = s_w[stage][(8 * h + t) * BW + 32 * nb + r];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          acc[nb][t % CH] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc[nb][t % CH], 0, 0, 0);
+      }
+      stage = stage + 1 == kStages ? 0 : stage + 1;
+    }
+    // C/D map: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) {
+      const int col = c0 + 32 * nb + r;
+      if (col < a.k) {
+        float v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          v[e] = acc[nb][0][e];
+#pragma unroll
+          for (int c = 1; c < CH; ++c) v[e] += acc[nb][c][e];
+        }
+        if (a.accumulate) {
+          // all 16 old values in flight at once (the wait for them also drains the ring's loads)
+          float old[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int64_t i = i0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h;
+            old[e] = i < a.m ? ctr_ldg(a.gx + i * a.ldgx + col) : 0.0f;
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] += old[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int64_t i = i0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (i < a.m) ctr_stg(a.gx + i * a.ldgx + col, v[e]);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+bool ctr_gemm_dlds_dx_ok(const float* w, int64_t ldw, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
+                         int64_t m, int n, int k, int act) {
+  if (n % kBK || n < kBK || k % 4 || k < 16 || m < 1) return false;
+  if (act != CTR_ACT_NONE && (!y || ldy % 4 || !ctr_aligned16(y))) return false;
+  return ctr_aligned16(w) && ctr_aligned16(gy) && ldw % 4 == 0 && ldgy % 4 == 0;
+}
+
+int ctr_gemm_dlds_dx(const float* w, int64_t ldw, const float* y, int64_t ldy, const float* gy, int64_t ldgy, float* gx,
+                     int64_t ldgx, int accumulate, int64_t m, int n, int k, int act, hipStream_t st) {
+  const int nt = k <= 32 ? 1 : (k <= 64 ? 2 : 4);
+  const int64_t mtiles = ctr_ceil_div(m, kBM);
+  const int64_t ny = ctr_ceil_div(k, 32 * nt);
+  int64_t gx_ = ctr_ceil_div(256 * 2, ny);
+  if (gx_ > mtiles) gx_ = mtiles;
+  if (gx_ < 1) gx_ = 1;
+  CTR_REQUIRE(ny <= 65535, CTR_ELIMIT);
+  const DxArgs a{gy, ldgy, act == CTR_ACT_NONE ? nullptr : y, ldy, w, ldw, gx, ldgx, m, n, k, accumulate};
+  const dim3 grid((unsigned)gx_, (unsigned)ny);
+#define CTR_DX(NT_, ACT_) hipLaunchKernelGGL((gemm_dx_dlds_kernel<NT_, ACT_>), grid, dim3(kThreads), 0, st, a)
+#define CTR_DX_ACT(NT_)                                      \
+  do {                                                       \
+    if (act == CTR_ACT_NONE) CTR_DX(NT_, CTR_ACT_NONE);      \
+    else if (act == CTR_ACT_RELU) CTR_DX(NT_, CTR_ACT_RELU); \
+    else CTR_DX(NT_, CTR_ACT_SIGMOID);                       \
+  } while (0)
+  if (nt == 1) CTR_DX_ACT(1);
+  else if (nt == 2) CTR_DX_ACT(2);
+  else CTR_DX_ACT(4);
+#undef CTR_DX_ACT
+#undef CTR_DX
+  return ctr_launch_status();
+}

@@ -492,7 +492,11 @@ extern "C" int ctr_linear_bwd(const float* x, int64_t ldx, const float* w, int64
   gz.gy = plain(gy, ldgy, m, n);
   gz.y = plain(y ? y : gy, y ? ldy : ldgy, m, n);
   gz.act = act;
-  if (gx) {
+  if (gx && ctr_gemm_dlds_dx_ok(w, ldw, y, ldy, gy, ldgy, m, n, k, act)) {
+    // aligned operands, n % 16 == 0: gY, Y and W stream global -> LDS directly (gemm_dlds_dx.hip)
+    int rc = ctr_gemm_dlds_dx(w, ldw, y, ldy, gy, ldgy, gx, ldgx, accumulate_gx, m, n, k, act, st);
+    if (rc != CTR_OK) return rc;
+  } else if (gx) {
     // gX[m][kcol] = sum_n gZ[m][n] W[n][kcol]: contraction = n
     StoreEpi e{gx, ldgx, accumulate_gx};
     int rc = launch<KC, KS>(gz, plain(w, ldw, n, k), e, m, k, n, 1, nullptr, st);
