@@ -9,9 +9,12 @@
 // choosing WHICH global chunk each lane fetches: slot q of a stage (16 B each, row = q/4) holds
 // k-chunk (q & 3) ^ ((row >> 1) & 3) of its row -- the 8 rows a quarter-wave reads with one
 // ds_read_b128 then cover all 32 banks.
-// Requirements (else ctr_linear_fwd keeps the tile kernel): K % 16 == 0, X / W rows 16-byte
-// aligned (ld % 4 == 0).  Rows past M / N are clamped to the last row: their products are
-// computed and dropped.
+// The 16-byte direct loads only need 4-byte aligned addresses (measured: rows with an odd leading
+// dimension run at the same rate), so any X / W layout with K >= 16 is taken.  Rows past M / N are
+// clamped to the last row: their products are computed and dropped.  Contraction tail (K % 16 != 0):
+// a chunk that would cross the end of its row is fetched from K-4 instead, so no load ever leaves
+// the matrix; the X fragment zeroes the positions that are duplicates or past K, W is left as is
+// (finite, multiplied by zero).
 #include "ctr_common.h"
 
 namespace {
@@ -41,7 +44,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // fetch one operand tile (ROWS x 16 floats) into a stage: chunk slot q = 64*wave + lane + 256*i
 template <int ROWS>
 __device__ __forceinline__ void fetch(float* stage, const float* __restrict__ src, int64_t ld, int64_t row0,
-                                      int64_t rows_total, int64_t k0, int lane, int wave) {
+                                      int64_t rows_total, int64_t k0, int64_t k_total, int lane, int wave) {
   constexpr int kChunks = ROWS * 4;
   constexpr int kIters = (kChunks + kThreads - 1) / kThreads;
 #pragma unroll
@@ -55,7 +58,9 @@ __device__ __forceinline__ void fetch(float* stage, const float* __restrict__ sr
     const int row = q >> 2, c = (q & 3) ^ ((row >> 1) & 3);
     int64_t gr = row0 + row;
     gr = gr < rows_total ? gr : rows_total - 1;
-    const float* g = src + gr * ld + k0 + c * 4;
+    int64_t kc = k0 + c * 4;
+    kc = kc < k_total - 4 ? kc : k_total - 4;
+    const float* g = src + gr * ld + kc;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)(stage + q0 * 4), 16, 0, 0);
   }
@@ -94,7 +99,8 @@ gemm_fwd_dlds_kernel(const DldsArgs a) {
   const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t mtiles = (a.m + kBM - 1) / kBM;
   const int64_t j0 = (int64_t)blockIdx.y * BN;
-  const int nk = (int)(a.k / kBK);
+  const int nk = (int)((a.k + kBK - 1) / kBK);
+  const bool ktail = a.k % kBK != 0;
   int64_t tile = blockIdx.x;
   if (tile >= mtiles) return;
 
@@ -117,8 +123,8 @@ gemm_fwd_dlds_kernel(const DldsArgs a) {
     }
   };
   auto issue = [&](int stage, int64_t t, int k) {
-    fetch<kBM>(s_a[stage], a.x, a.ldx, t * kBM, a.m, (int64_t)k * kBK, lane0, wave);
-    fetch<BN>(s_b[stage], a.w, a.ldw, j0, a.n, (int64_t)k * kBK, lane0, wave);
+    fetch<kBM>(s_a[stage], a.x, a.ldx, t * kBM, a.m, (int64_t)k * kBK, a.k, lane0, wave);
+    fetch<BN>(s_b[stage], a.w, a.ldw, j0, a.n, (int64_t)k * kBK, a.k, lane0, wave);
   };
   // slots g+1 and g+2 relative to the one being multiplied
   int64_t t1 = tile, t2;
@@ -174,6 +180,17 @@ gemm_fwd_dlds_kernel(const DldsArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]),
                        "+v"(fb[2][0]), "+v"(fb[2][1]), "+v"(fb[3][0]), "+v"(fb[3][1]));
+      if (ktail && ks == nk - 1) {
+        // chunk (2h + v) of the last step starts at kc; fetched from K-4 when it crosses K: its first
+        // kc + 4 - K positions then repeat the previous chunk (or everything is past K)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          const int64_t over = (int64_t)ks * kBK + (2 * h + v) * 4 + 4 - a.k;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < over) fa[v][j] = 0.0f;
+        }
+      }
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -187,17 +204,28 @@ gemm_fwd_dlds_kernel(const DldsArgs a) {
     for (int n = 0; n < NT; ++n) {
       const int64_t j = j0 + 32 * n + r;
       if (j < a.n) {
+        float v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          v[e] = acc[n][0][e] + bj[n];
+#pragma unroll
+          for (int c = 1; c < CH; ++c) v[e] += acc[n][c][e];
+        }
+        if (a.res) {
+          // all 16 residual values in flight at once (the wait for them also drains the ring's loads)
+          float rv[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int64_t i = i0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h;
+            rv[e] = i < a.m ? ctr_ldg(a.res + i * a.ldr + j) : 0.0f;
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] += rv[e];
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int64_t i = i0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h;
-          float v = acc[n][0][e];
-#pragma unroll
-          for (int c = 1; c < CH; ++c) v += acc[n][c][e];
-          if (i < a.m) {
-            float z = v + bj[n];
-            if (a.res) z += a.res[i * a.ldr + j];
-            a.y[i * a.ldy + j] = ctr_act(z, a.act);
-          }
+          if (i < a.m) ctr_stg(a.y + i * a.ldy + j, ctr_act(v[e], a.act));
         }
       }
     }
@@ -207,11 +235,10 @@ gemm_fwd_dlds_kernel(const DldsArgs a) {
 }  // namespace
 
 bool ctr_gemm_dlds_ok(const float* x, int64_t ldx, const float* w, int64_t ldw, int64_t m, int n, int k) {
-  return k % kBK == 0 && k >= kBK && m >= 1 && n >= 1 && ctr_aligned16(x) && ctr_aligned16(w) && ldx % 4 == 0 &&
-         ldw % 4 == 0;
+  return k >= kBK && m >= 1 && n >= 1;
 }
 
-int ctr_gemm_dlds_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* res,
+static int launch_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* res,
                       int64_t ldr, float* y, int64_t ldy, int64_t m, int n, int k, int act, hipStream_t st) {
   const int nt = n <= 32 ? 1 : (n <= 64 ? 2 : 4);
   const int64_t mtiles = ctr_ceil_div(m, kBM);
@@ -226,4 +253,21 @@ int ctr_gemm_dlds_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, 
   else if (nt == 2) hipLaunchKernelGGL(gemm_fwd_dlds_kernel<2>, grid, dim3(kThreads), 0, st, a);
   else hipLaunchKernelGGL(gemm_fwd_dlds_kernel<4>, grid, dim3(kThreads), 0, st, a);
   return ctr_launch_status();
+}
+
+int ctr_gemm_dlds_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* res,
+                      int64_t ldr, float* y, int64_t ldy, int64_t m, int n, int k, int act, hipStream_t st) {
+  // 17..64 units past a multiple of 128 (161 = 128 + 33) would cost a whole, mostly empty 128-wide column
+  // of tiles: they get their own launch with a 64-wide tile (91 -> 79 us on 65536 x 161 x 256).  Fewer
+  // are not worth a second pass over X (641 = 5 * 128 + 1: 707 us in one launch, 750 split -- with a
+  // 32-wide tile or with the single-unit streaming kernel for the odd unit)
+  const int rem = n % 128;
+  if (n > 128 && rem > 16 && rem <= 64) {
+    const int main_n = n - rem;
+    int rc = launch_fwd(x, ldx, w, ldw, bias, res, ldr, y, ldy, m, main_n, k, act, st);
+    if (rc != CTR_OK) return rc;
+    return launch_fwd(x, ldx, w + (int64_t)main_n * ldw, ldw, bias ? bias + main_n : nullptr, res ? res + main_n : nullptr,
+                      ldr, y + main_n, ldy, m, rem, k, act, st);
+  }
+  return launch_fwd(x, ldx, w, ldw, bias, res, ldr, y, ldy, m, n, k, act, st);
 }

@@ -7,7 +7,7 @@
 // floats per half-wave and instruction, conflict-free without any swizzle, and the LDS image is the
 // plain row-major tile the direct loads produce.  act'(Y) is applied to the gY values as they are
 // read; rows past the end of a workgroup's row range are zeroed there too (their loads are clamped
-// to a valid row).
+// to a valid row).  The 16-byte loads only need 4-byte aligned addresses; see fetch() for the column tails.
 //
 // Output tile: 128 x 32*NT per 256-thread workgroup (which side is units: see SWAP), the batch cut into
 // `parts` row ranges (multiples of 16 rows); every workgroup stores its partial tile into its part's
@@ -64,8 +64,10 @@ __device__ __forceinline__ void fetch(float* stage, const float* __restrict__ sr
     const int row = q / kPerRow, cc = q % kPerRow;
     int64_t gr = row0 + row;
     gr = gr < row_last ? gr : row_last;
+    // a chunk that would cross the end of the row (or lies past it) is fetched from 4 floats before
+    // the end: no load leaves the matrix, the reader adds the shift (tail_shift), the rest is dropped
     int col = col0 + cc * 4;
-    col = col < cols_total ? col : 0;  // columns past the matrix: any valid address, the products are dropped
+    col = col < cols_total - 4 ? col : cols_total - 4;
     dma16(src + gr * ld + col, __builtin_amdgcn_readfirstlane(lds_addr(stage + q0 * 4)));
   }
 }
@@ -73,6 +75,12 @@ __device__ __forceinline__ void fetch(float* stage, const float* __restrict__ sr
 // SWAP = false: the 128-wide side of the tile are units (operand gZ, columns n0..), the 32*NT side inputs (X).
 // SWAP = true : the 128-wide side are inputs (X, columns k0..), the 32*NT side units (gZ) -- for layers with
 //               fewer than 128 units, which would leave half of the unswapped tile empty.
+// logical column `col` of a matrix with `total` columns sits this many floats further right in its
+// (shifted) last chunk
+__device__ __forceinline__ int tail_shift(int col, int total) {
+  return (total & 3) && col >= (total & ~3) && col < total ? 4 - (total & 3) : 0;
+}
+
 template <int NT, int ACT, bool SWAP>
 __global__ void __launch_bounds__(kThreads, 2)
 gemm_dw_dlds_kernel(const DwArgs a) {
@@ -95,6 +103,12 @@ gemm_dw_dlds_kernel(const DwArgs a) {
   const int64_t mb = (int64_t)blockIdx.x * a.rows_per_part;
   const int64_t me = mb + a.rows_per_part < a.m ? mb + a.rows_per_part : a.m;
   const int steps = (int)((me - mb + kBK - 1) / kBK);
+
+  // LDS columns of this lane's operand elements (A side: 32*wave + r, B side: 32*nb + r)
+  const int acol = 32 * wave + r + tail_shift((SWAP ? k0 : n0) + 32 * wave + r, SWAP ? a.k : a.n);
+  int bcol[NT];
+#pragma unroll
+  for (int nb = 0; nb < NT; ++nb) bcol[nb] = 32 * nb + r + tail_shift((SWAP ? n0 : k0) + 32 * nb + r, SWAP ? a.n : a.k);
 
   floatx16 acc[NT];
 #pragma unroll
@@ -136,9 +150,9 @@ gemm_dw_dlds_kernel(const DwArgs a) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       if (SWAP) {
-        fa[t] = s_x[stage][(8 * h + t) * XW + 32 * wave + r];
+        fa[t] = s_x[stage][(8 * h + t) * XW + acol];
       } else {
-        fa[t] = gz(t, 32 * wave + r);
+        fa[t] = gz(t, acol);
         bsum[0] += fa[t];
       }
     }
@@ -148,10 +162,10 @@ gemm_dw_dlds_kernel(const DwArgs a) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         if (SWAP) {
-          fb[t] = gz(t, 32 * nb + r);
+          fb[t] = gz(t, bcol[nb]);
           bsum[nb] += fb[t];
         } else {
-          fb[t] = s_x[stage][(8 * h + t) * XW + 32 * nb + r];
+          fb[t] = s_x[stage][(8 * h + t) * XW + bcol[nb]];
         }
       }
 #pragma unroll
@@ -186,10 +200,9 @@ gemm_dw_dlds_kernel(const DwArgs a) {
 
 bool ctr_gemm_dlds_dw_ok(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
                          const float* gw, int64_t ldgw, int64_t m, int n, int k, int act) {
-  if (!gw || ldgw != k || n % 4 || k % 4 || m < 4096) return false;
+  if (!gw || ldgw != k || m < 4096) return false;
   if (!((n >= 96 && k >= 32) || (k >= 96 && n >= 32))) return false;
-  if (act != CTR_ACT_NONE && (!y || ldy % 4 || !ctr_aligned16(y))) return false;
-  return ctr_aligned16(x) && ctr_aligned16(gy) && ldx % 4 == 0 && ldgy % 4 == 0;
+  return act == CTR_ACT_NONE || y != nullptr;
 }
 
 int ctr_gemm_dlds_dw(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gy, int64_t ldgy, float* gw,

@@ -6,7 +6,11 @@
 // contracts 16 units.  gY / Y tiles are [128][16] with the chunk swizzle of gemm_dlds.hip (read with
 // ds_read_b128 along the units), the W tile is the plain row-major [16][32*NT] block and is read down
 // its rows (32 consecutive floats per half-wave: conflict-free).  act'(Y) is applied as gY is read.
-// Requirements (else the tile kernel of linear.hip runs): n % 16 == 0, k % 4 == 0, 16-byte aligned rows.
+// The 16-byte direct loads only need 4-byte aligned addresses, so any layout with n, k >= 16 is taken.
+// No load leaves its matrix: a chunk that would cross the end of a row is fetched from 4 floats before
+// the end instead.  Along the units (contraction tail, n % 16 != 0) the gY fragment zeroes the
+// positions that are then duplicates or past n; along W's columns (k % 4 != 0) the reader adds the
+// shift to its column index.
 #include "ctr_common.h"
 
 namespace {
@@ -41,7 +45,7 @@ __device__ __forceinline__ uint32_t lds_addr(const float* p) {
 
 // [128 rows][16 units] tile, slot q (16 B) = row q/4, unit chunk (q & 3) ^ ((row >> 1) & 3)
 __device__ __forceinline__ void fetch_rows(float* stage, const float* __restrict__ src, int64_t ld, int64_t row0,
-                                           int64_t rows_total, int u0, int lane, int wave) {
+                                           int64_t rows_total, int u0, int u_total, int lane, int wave) {
 #pragma unroll
   for (int i = 0; i < kBM * 4 / kThreads; ++i) {
     const int q0 = 64 * wave + kThreads * i;
@@ -49,14 +53,22 @@ __device__ __forceinline__ void fetch_rows(float* stage, const float* __restrict
     const int row = q >> 2, c = (q & 3) ^ ((row >> 1) & 3);
     int64_t gr = row0 + row;
     gr = gr < rows_total ? gr : rows_total - 1;
-    dma16(src + gr * ld + u0 + c * 4, __builtin_amdgcn_readfirstlane(lds_addr(stage + q0 * 4)));
+    int u = u0 + c * 4;
+    u = u < u_total - 4 ? u : u_total - 4;
+    dma16(src + gr * ld + u, __builtin_amdgcn_readfirstlane(lds_addr(stage + q0 * 4)));
   }
+}
+
+// logical column `col` of a matrix with `total` columns sits this many floats further right in its
+// (shifted) last chunk
+__device__ __forceinline__ int tail_shift(int col, int total) {
+  return (total & 3) && col >= (total & ~3) && col < total ? 4 - (total & 3) : 0;
 }
 
 // plain [16 units][W columns] block of the weight
 template <int W>
-__device__ __forceinline__ void fetch_w(float* stage, const float* __restrict__ w, int64_t ldw, int u0, int col0,
-                                        int cols_total, int lane, int wave) {
+__device__ __forceinline__ void fetch_w(float* stage, const float* __restrict__ w, int64_t ldw, int u0, int u_total,
+                                        int col0, int cols_total, int lane, int wave) {
   constexpr int kPerRow = W / 4, kChunks = 16 * kPerRow;
   constexpr int kIters = (kChunks + kThreads - 1) / kThreads;
 #pragma unroll
@@ -66,8 +78,12 @@ __device__ __forceinline__ void fetch_w(float* stage, const float* __restrict__ 
     const int q = q0 + lane;
     const int row = q / kPerRow, cc = q % kPerRow;
     int col = col0 + cc * 4;
-    col = col < cols_total ? col : 0;
-    dma16(w + (int64_t)(u0 + row) * ldw + col, __builtin_amdgcn_readfirstlane(lds_addr(stage + q0 * 4)));
+    col = col < cols_total - 4 ? col : cols_total - 4;
+    // row = 4*chunk + j of the step follows the unit the gY fragment holds at that position
+    // (fetch_rows: chunks crossing n start at n-4)
+    int u = u0 + (row & ~3);
+    u = (u < u_total - 4 ? u : u_total - 4) + (row & 3);
+    dma16(w + (int64_t)u * ldw + col, __builtin_amdgcn_readfirstlane(lds_addr(stage + q0 * 4)));
   }
 }
 
@@ -85,7 +101,8 @@ gemm_dx_dlds_kernel(const DxArgs a) {
   const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t mtiles = (a.m + kBM - 1) / kBM;
   const int c0 = blockIdx.y * BW;
-  const int nk = a.n / kBK;
+  const int nk = (a.n + kBK - 1) / kBK;
+  const bool utail = a.n % kBK != 0;
   int64_t tile = blockIdx.x;
   if (tile >= mtiles) return;
 
@@ -99,9 +116,9 @@ gemm_dx_dlds_kernel(const DxArgs a) {
     }
   };
   auto issue = [&](int stage, int64_t t, int ks) {
-    fetch_rows(s_gy[stage], a.gy, a.ldgy, t * kBM, a.m, ks * kBK, lane0, wave);
-    if (has_y) fetch_rows(s_y[stage], a.y, a.ldy, t * kBM, a.m, ks * kBK, lane0, wave);
-    fetch_w<BW>(s_w[stage], a.w, a.ldw, ks * kBK, c0, a.k, lane0, wave);
+    fetch_rows(s_gy[stage], a.gy, a.ldgy, t * kBM, a.m, ks * kBK, a.n, lane0, wave);
+    if (has_y) fetch_rows(s_y[stage], a.y, a.ldy, t * kBM, a.m, ks * kBK, a.n, lane0, wave);
+    fetch_w<BW>(s_w[stage], a.w, a.ldw, ks * kBK, a.n, c0, a.k, lane0, wave);
   };
   int64_t t1 = tile, t2;
   int k1 = 0, k2;
@@ -118,6 +135,9 @@ gemm_dx_dlds_kernel(const DxArgs a) {
     asm volatile("" : "+v"(lane));
     const int r = lane & 31, h = lane >> 5;
     const int arow = 32 * wave + r, sw = (arow >> 1) & 3;
+    int wcol[NT];
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) wcol[nb] = 32 * nb + r + tail_shift(c0 + 32 * nb + r, a.k);
 #pragma unroll
     for (int nb = 0; nb < NT; ++nb)
 #pragma unroll
@@ -147,12 +167,20 @@ gemm_dx_dlds_kernel(const DxArgs a) {
           fa[4 * v + 2] *= ctr_act_grad(yv.z, ACT);
           fa[4 * v + 3] *= ctr_act_grad(yv.w, ACT);
         }
+        if (utail && ks == nk - 1) {
+          // chunk (2h + v) of the last step was fetched from n-4 if it crosses n: its first `over`
+          // positions repeat the previous chunk (or all of it is past n)
+          const int over = ks * kBK + (2 * h + v) * 4 + 4 - a.n;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < over) fa[4 * v + j] = 0.0f;
+        }
       }
 #pragma unroll
       for (int nb = 0; nb < NT; ++nb) {
         float fb[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) fb[t] = s_w[stage][(8 * h + t) * BW + 32 * nb + r];
+        for (int t = 0; t < 8; ++t) fb[t] = s_w[stage][(8 * h + t) * BW + wcol[nb]];
 #pragma unroll
         for (int t = 0; t < 8; ++t)
           acc[nb][t % CH] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc[nb][t % CH], 0, 0, 0);
@@ -196,12 +224,11 @@ gemm_dx_dlds_kernel(const DxArgs a) {
 
 bool ctr_gemm_dlds_dx_ok(const float* w, int64_t ldw, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
                          int64_t m, int n, int k, int act) {
-  if (n % kBK || n < kBK || k % 4 || k < 16 || m < 1) return false;
-  if (act != CTR_ACT_NONE && (!y || ldy % 4 || !ctr_aligned16(y))) return false;
-  return ctr_aligned16(w) && ctr_aligned16(gy) && ldw % 4 == 0 && ldgy % 4 == 0;
+  if (n < kBK || k < 16 || m < 1) return false;
+  return act == CTR_ACT_NONE || y != nullptr;
 }
 
-int ctr_gemm_dlds_dx(const float* w, int64_t ldw, const float* y, int64_t ldy, const float* gy, int64_t ldgy, float* gx,
+static int launch_dx(const float* w, int64_t ldw, const float* y, int64_t ldy, const float* gy, int64_t ldgy, float* gx,
                      int64_t ldgx, int accumulate, int64_t m, int n, int k, int act, hipStream_t st) {
   const int nt = k <= 32 ? 1 : (k <= 64 ? 2 : 4);
   const int64_t mtiles = ctr_ceil_div(m, kBM);
@@ -225,4 +252,19 @@ int ctr_gemm_dlds_dx(const float* w, int64_t ldw, const float* y, int64_t ldy, c
 #undef CTR_DX_ACT
 #undef CTR_DX
   return ctr_launch_status();
+}
+
+int ctr_gemm_dlds_dx(const float* w, int64_t ldw, const float* y, int64_t ldy, const float* gy, int64_t ldgy, float* gx,
+                     int64_t ldgx, int accumulate, int64_t m, int n, int k, int act, hipStream_t st) {
+  // a few input columns past a multiple of 128 get their own launch with a narrow tile (see gemm_dlds.hip);
+  // the remainder needs >= 4 columns for its loads to stay inside W's rows, so it borrows from the main part
+  int rem = k % 128;
+  if (k > 128 && rem != 0 && rem <= 64) {
+    if (rem < 4) rem += 32;
+    const int main_k = k - rem;
+    int rc = launch_dx(w, ldw, y, ldy, gy, ldgy, gx, ldgx, accumulate, m, n, main_k, act, st);
+    if (rc != CTR_OK) return rc;
+    return launch_dx(w + main_k, ldw, y, ldy, gy, ldgy, gx + main_k, ldgx, accumulate, m, n, rem, act, st);
+  }
+  return launch_dx(w, ldw, y, ldy, gy, ldgy, gx, ldgx, accumulate, m, n, k, act, st);
 }

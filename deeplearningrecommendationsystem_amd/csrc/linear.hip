@@ -445,8 +445,8 @@ extern "C" int ctr_linear_fwd(const float* x, int64_t ldx, const float* w, int64
   CTR_REQUIRE(act >= CTR_ACT_NONE && act <= CTR_ACT_SIGMOID, CTR_EINVAL);
   if (n == 1 && ctr_n1_supported(k))
     return ctr_n1_fwd(x, ldx, w, bias, residual, ldr, y, ldy, m, k, act, (hipStream_t)stream);
-  // aligned operands with K % 16 == 0 stream global -> LDS directly (gemm_dlds.hip: 1.1-1.5x the tile kernel)
-  if (!residual && ctr_gemm_dlds_ok(x, ldx, w, ldw, m, n, k))
+  // K >= 16: operands stream global -> LDS directly (gemm_dlds.hip: 1.1-1.6x the tile kernel)
+  if (ctr_gemm_dlds_ok(x, ldx, w, ldw, m, n, k))
     return ctr_gemm_dlds_fwd(x, ldx, w, ldw, bias, residual, ldr, y, ldy, m, n, k, act, (hipStream_t)stream);
   FwdEpi e{y, ldy, bias, residual, ldr, act};
   return launch<KC, KC>(plain(x, ldx, m, k), plain(w, ldw, n, k), e, m, n, k, 1, nullptr, (hipStream_t)stream);

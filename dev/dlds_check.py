@@ -5,7 +5,7 @@ import torch
 from deeplearningrecommendationsystem_amd import ops
 dev = "cuda:0"
 torch.manual_seed(0)
-for m, n, k, act in [(1000, 128, 64, 1), (129, 33, 16, 0), (65536, 64, 128, 1), (4097, 200, 160, 2), (70000, 8, 16, 1), (5, 300, 48, 1), (65536, 256, 512, 1), (65536, 640, 640, 1), (4097, 160, 256, 1)]:
+for m, n, k, act in [(1000, 128, 64, 1), (129, 33, 16, 0), (65536, 64, 128, 1), (4097, 200, 160, 2), (70000, 8, 16, 1), (5, 300, 48, 1), (65536, 256, 512, 1), (65536, 641, 641, 1), (4097, 161, 256, 1), (4097, 256, 161, 2), (1000, 33, 17, 0), (300, 70, 103, 1), (513, 100, 30, 1)]:
     x = torch.randn(m, k, device=dev); w = torch.randn(n, k, device=dev) / k ** 0.5; b = torch.randn(n, device=dev)
     y = ops.linear_fwd(x, w, b, act)
     z = x.double() @ w.double().t() + b.double()
