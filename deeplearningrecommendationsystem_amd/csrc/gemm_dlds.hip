@@ -243,7 +243,7 @@ static int launch_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, 
   const int nt = n <= 32 ? 1 : (n <= 64 ? 2 : 4);
   const int64_t mtiles = ctr_ceil_div(m, kBM);
   const int64_t ny = ctr_ceil_div(n, 32 * nt);
-  int64_t gx = ctr_ceil_div(256 * 3, ny);
+  int64_t gx = 256 * 3 / ny;  // rounded down: a workgroup beyond the resident 3 per CU would start a second round
   if (gx > mtiles) gx = mtiles;
   if (gx < 1) gx = 1;
   CTR_REQUIRE(ny <= 65535, CTR_ELIMIT);

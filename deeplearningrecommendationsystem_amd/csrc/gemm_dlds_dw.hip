@@ -220,7 +220,9 @@ int ctr_gemm_dlds_dw(const float* x, int64_t ldx, const float* y, int64_t ldy, c
   const int64_t slab = (int64_t)n * k + (gb ? n : 0);
   // one round of the 2 resident workgroups per CU: more, shorter row ranges only add slab traffic (measured:
   // 65536 x 256 x 512 takes 200 us with 512 workgroups, 221-228 us with 768-1536)
-  int64_t parts = ctr_ceil_div(256 * 2, ty * tz);
+  // (rounded down: 540 workgroups would run as a full round plus a round of 28)
+  int64_t parts = 256 * 2 / (ty * tz);
+  if (parts < 1) parts = 1;
   if (parts * slab > workspace_floats) parts = workspace_floats / slab;
   if (parts < 1) return CTR_ELIMIT;
   int64_t rows = ctr_ceil_div(ctr_ceil_div(m, parts), kBK) * kBK;

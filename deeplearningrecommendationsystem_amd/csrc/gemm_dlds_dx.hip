@@ -233,7 +233,7 @@ static int launch_dx(const float* w, int64_t ldw, const float* y, int64_t ldy, c
   const int nt = k <= 32 ? 1 : (k <= 64 ? 2 : 4);
   const int64_t mtiles = ctr_ceil_div(m, kBM);
   const int64_t ny = ctr_ceil_div(k, 32 * nt);
-  int64_t gx_ = ctr_ceil_div(256 * 2, ny);
+  int64_t gx_ = 256 * 2 / ny;  // rounded down: a workgroup beyond the resident 2 per CU would start a second round
   if (gx_ > mtiles) gx_ = mtiles;
   if (gx_ < 1) gx_ = 1;
   CTR_REQUIRE(ny <= 65535, CTR_ELIMIT);
