@@ -176,6 +176,9 @@ LINEAR_SHAPES = [
     (300, 128, 96), (2048, 161, 256), (700, 256, 161), (257, 512, 48), (4096, 8, 16),
     # few units on both sides over a long batch: the streaming kernels of linear_skinny.hip
     (70001, 48, 16), (65536, 64, 32), (66000, 8, 8), (65537, 4, 16),
+    # direct-to-LDS kernels (gemm_dlds*.hip): sizes that are not multiples of the 16-float step / 4-float
+    # chunk on either side (shifted last chunks, fragment masks), both dW orientations, split launches
+    (4500, 130, 131), (4100, 97, 35), (4200, 33, 103), (4097, 19, 30), (5000, 200, 17), (4099, 161, 289),
 ]
 
 
@@ -231,6 +234,35 @@ def test_linear_strided_views_residual_and_accumulate(ops):
     gx = torch.ones(m, k, device=DEV)
     ops.linear_bwd(dbig[:, 10:10 + k], w.to(DEV), None, gy.to(DEV), 0, gx, None, None, accumulate_gx=True)
     torch.testing.assert_close(gx.cpu(), (1.0 + gy.double() @ w.double()).float(), rtol=1e-5, atol=1e-5)
+
+
+def test_linear_direct_to_lds_odd_leading_dimensions(ops):
+    """operands cut out of wider buffers with ODD row strides (rows only 4-byte aligned), residual,
+    accumulate_gx, at sizes the direct-to-LDS kernels take (k, n >= 16; m >= 4096 for dW)"""
+    g = torch.Generator().manual_seed(21)
+    m, n, k = 4300, 161, 163
+    xb, wb = torch.randn(m, k + 6, generator=g), torch.randn(n, k + 2, generator=g) / k ** 0.5
+    x, w, b = xb[:, 3:3 + k], wb[:, 1:1 + k], torch.randn(n, generator=g)
+    resb, gyb = torch.randn(m, n + 4, generator=g), torch.randn(m, n + 2, generator=g)
+    res, gy = resb[:, 2:2 + n], gyb[:, 1:1 + n]
+    dxb, dwb, dresb, dgyb = xb.to(DEV), wb.to(DEV), resb.to(DEV), gyb.to(DEV)
+    dx, dw, dres, dgy = dxb[:, 3:3 + k], dwb[:, 1:1 + k], dresb[:, 2:2 + n], dgyb[:, 1:1 + n]
+    ybuf = torch.full((m, n + 3), 7.0, device=DEV)
+    ops.linear_fwd(dx, dw, b.to(DEV), 1, out=ybuf[:, 1:1 + n], residual=dres)
+    z = x.double() @ w.double().T + b.double() + res.double()
+    torch.testing.assert_close(ybuf[:, 1:1 + n].cpu(), torch.relu(z).float(), rtol=1e-5, atol=4e-6)
+    assert torch.equal(ybuf[:, :1].cpu(), torch.full((m, 1), 7.0)) and torch.equal(ybuf[:, 1 + n:].cpu(), torch.full((m, 2), 7.0))
+    # backward through the relu, gX accumulated into a strided view
+    yd = torch.relu(z)
+    gz = gy.double() * (yd > 0)
+    gxbuf = torch.ones(m, k + 5, device=DEV)
+    gw, gb = torch.zeros(n, k, device=DEV), torch.zeros(n, device=DEV)
+    ops.linear_bwd(dx, dw, ybuf[:, 1:1 + n], dgy, 1, gxbuf[:, 2:2 + k], gw, gb, accumulate_gx=True)
+    torch.testing.assert_close(gxbuf[:, 2:2 + k].cpu(), (1.0 + gz @ w.double()).float(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(gxbuf[:, :2].cpu(), torch.ones(m, 2)) and torch.equal(gxbuf[:, 2 + k:].cpu(), torch.ones(m, 3))
+    scale = m ** 0.5
+    torch.testing.assert_close(gw.cpu(), (gz.T @ x.double()).float(), rtol=1e-5, atol=2e-6 * scale)
+    torch.testing.assert_close(gb.cpu(), gz.sum(0).float(), rtol=1e-5, atol=2e-6 * scale)
 
 
 def test_mf_fused_kernels(ops):
