@@ -10,7 +10,7 @@
 // k-chunk (q & 3) ^ ((row >> 1) & 3) of its row -- the 8 rows a quarter-wave reads with one
 // ds_read_b128 then cover all 32 banks.
 // The 16-byte direct loads only need 4-byte aligned addresses (measured: rows with an odd leading
-// dimension run at the same rate), so any X / W layout with K >= 16 is taken.  Rows past M / N are
+// dimension run at the same rate), so any X / W layout with K >= 4 is taken.  Rows past M / N are
 // clamped to the last row: their products are computed and dropped.  Contraction tail (K % 16 != 0):
 // a chunk that would cross the end of its row is fetched from K-4 instead, so no load ever leaves
 // the matrix; the X fragment zeroes the positions that are duplicates or past K, W is left as is
@@ -235,7 +235,7 @@ gemm_fwd_dlds_kernel(const DldsArgs a) {
 }  // namespace
 
 bool ctr_gemm_dlds_ok(const float* x, int64_t ldx, const float* w, int64_t ldw, int64_t m, int n, int k) {
-  return k >= kBK && m >= 1 && n >= 1;
+  return k >= 4 && m >= 1 && n >= 1;  // a chunk is fetched from k-4 at the latest
 }
 
 static int launch_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* res,

@@ -6,7 +6,7 @@
 // contracts 16 units.  gY / Y tiles are [128][16] with the chunk swizzle of gemm_dlds.hip (read with
 // ds_read_b128 along the units), the W tile is the plain row-major [16][32*NT] block and is read down
 // its rows (32 consecutive floats per half-wave: conflict-free).  act'(Y) is applied as gY is read.
-// The 16-byte direct loads only need 4-byte aligned addresses, so any layout with n, k >= 16 is taken.
+// The 16-byte direct loads only need 4-byte aligned addresses, so any layout with n, k >= 4 is taken.
 // No load leaves its matrix: a chunk that would cross the end of a row is fetched from 4 floats before
 // the end instead.  Along the units (contraction tail, n % 16 != 0) the gY fragment zeroes the
 // positions that are then duplicates or past n; along W's columns (k % 4 != 0) the reader adds the
@@ -224,7 +224,7 @@ gemm_dx_dlds_kernel(const DxArgs a) {
 
 bool ctr_gemm_dlds_dx_ok(const float* w, int64_t ldw, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
                          int64_t m, int n, int k, int act) {
-  if (n < kBK || k < 16 || m < 1) return false;
+  if (n < 4 || k < 4 || m < 1) return false;  // a chunk is fetched from n-4 / k-4 at the latest
   return act == CTR_ACT_NONE || y != nullptr;
 }
 
