@@ -11,7 +11,7 @@ import os; f=max(glob.glob(f'/root/repo/gpurun_out/prof_{w}/*/*kernel_stats.csv'
 rows=list(csv.DictReader(open(f)))
 tot=sum(float(r['TotalDurationNs']) for r in rows)
 print(f"=== {w}: total kernel time per step {tot/23/1e3:.1f} us (23 steps incl warmup+profile pass)")
-for r in rows[:14]:
+for r in rows[:24]:
     n=r['Name'].replace('(anonymous namespace)::','').replace('void ','')[:86]
     print(f"  {int(r['Calls']):5d} {float(r['AverageNs'])/1e3:9.1f} us {float(r['Percentage']):6.2f}%  {n}")
 PY
