@@ -1,12 +1,29 @@
 """``BCELoss`` -- drop-in for the ``torch.nn.BCELoss()`` every reference script builds
-(e.g. scripts/pnn.py:54): mean reduction, log terms clamped at -100.  Forward is one pass +
-a fixed-order reduction of <= 256 partials (torch: elementwise kernel + a single-workgroup
-mean), backward one pass."""
+(e.g. scripts/pnn.py:54): mean reduction, log terms clamped at -100.  Forward is ONE launch: a pass
+over the samples whose last workgroup sums the <= 256 partials in a fixed order (torch: elementwise
+kernel + a single-workgroup mean), backward one pass."""
 from __future__ import annotations
 
 import torch
 
 from . import _lib
+
+
+_tickets = {}
+
+
+def _ticket(device: torch.device) -> torch.Tensor:
+    """the zeroed device word ctr_bce_fwd finds its last workgroup with; the kernel leaves it zero.
+    One per device: losses of one device are issued from one stream at a time here (the trainer's
+    stream, or the hipGraph capture stream after its warm-up) -- a second stream computing a loss
+    CONCURRENTLY would need its own word.  Created outside any capture (a tensor made during
+    capture would add a fill to every replay)."""
+    t = _tickets.get(device.index)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("BCELoss: run one step before capturing (GraphedStep does) so its ticket exists")
+        t = _tickets[device.index] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
 
 
 class _BCEFunction(torch.autograd.Function):
@@ -20,7 +37,7 @@ class _BCEFunction(torch.autograd.Function):
         ws = torch.empty(256, dtype=torch.float32, device=prob.device)
         rc = _lib.load().ctr_bce_fwd(p.data_ptr(), p.stride(0) if p.numel() > 1 else 1, t.data_ptr(),
                                      t.stride(0) if t.numel() > 1 else 1, p.numel(), loss.data_ptr(),
-                                     ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+                                     ws.data_ptr(), ws.numel(), _ticket(prob.device).data_ptr(), _lib.stream_ptr())
         _lib.check(rc, "ctr_bce_fwd")
         ctx.save_for_backward(p, t)
         ctx.shape = prob.shape

@@ -323,9 +323,11 @@ int ctr_shard_bucket(const int64_t* ids, int64_t n, int world, int64_t* counts, 
 
 /* torch.nn.BCELoss() with mean reduction (every script, e.g. scripts/pnn.py:54):
  * loss[0] = mean_i -[t_i*max(log p_i,-100) + (1-t_i)*max(log(1-p_i),-100)].
- * prob/target: element i at [i*ld]; workspace: >= 256 floats of device scratch. */
+ * prob/target: element i at [i*ld]; workspace: >= 256 floats of device scratch; ticket: one device
+ * word that is ZERO on entry and zero again when the call has run (the single launch finds its
+ * last workgroup with it) -- allocate it once per stream, zeroed, and keep passing it. */
 int ctr_bce_fwd(const float* prob, int64_t ldp, const float* target, int64_t ldt, int64_t n, float* loss,
-                float* workspace, int64_t workspace_floats, void* stream);
+                float* workspace, int64_t workspace_floats, unsigned int* ticket, void* stream);
 /* gprob[i*ldg] = (p_i - t_i) / max(p_i (1-p_i), 1e-12) * gloss[0] / n */
 int ctr_bce_bwd(const float* prob, int64_t ldp, const float* target, int64_t ldt, int64_t n,
                 const float* gloss, float* gprob, int64_t ldg, void* stream);
