@@ -42,6 +42,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // one wave instruction: lane L's 16 bytes land at lds_base + 16 L
+// (m0 is a reserved register: the compiler only sets it right in front of an instruction that reads it,
+// never keeps a value there, and rejects it as a clobber)
 __device__ __forceinline__ void dma16(const float* g, uint32_t lds_base) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_base) : "memory");
 }

@@ -35,6 +35,8 @@ __device__ __forceinline__ void wait_vmcnt() {
   __builtin_amdgcn_s_waitcnt((N & 0xF) | (0x7 << 4) | (0xF << 8) | ((N >> 4) << 14));
 }
 
+// (m0 is a reserved register: the compiler only sets it right in front of an instruction that reads it,
+// never keeps a value there, and rejects it as a clobber)
 __device__ __forceinline__ void dma16(const float* g, uint32_t lds_base) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_base) : "memory");
 }
