@@ -79,6 +79,14 @@ struct NcfShape {  // model/neuralcf.py:23-27 at BASELINE configs[1]: 128 -> 64 
   static constexpr int K[5] = {128, 64, 32, 16, 8};
   static constexpr int ACT[5] = {CTR_ACT_RELU, CTR_ACT_RELU, CTR_ACT_RELU, CTR_ACT_RELU, CTR_ACT_NONE};
 };
+struct NcfTowerShape {  // the same tower without its 8 -> mf_dim projection, which the model folds into the head (fold_head.hip)
+  static constexpr int kWavesPerSimd = 1;  // 192 dW accumulator registers + the prefetch stage
+  static constexpr bool kFixed = true;
+  static constexpr int kLayers = 4;
+  static constexpr int N[4] = {64, 32, 16, 8};
+  static constexpr int K[4] = {128, 64, 32, 16};
+  static constexpr int ACT[4] = {CTR_ACT_RELU, CTR_ACT_RELU, CTR_ACT_RELU, CTR_ACT_RELU};
+};
 struct DienAttShape {  // model/dien.py:13-19 at BASELINE configs[4] (E = 16) on the folded [h, t] operand: 32 -> 64 -> 32 -> 1
   static constexpr int kWavesPerSimd = 2;  // small stack: <=256 registers and <=80 KB of LDS, two workgroups per CU
   static constexpr bool kFixed = true;
@@ -940,6 +948,11 @@ extern "C" int ctr_mlp_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp
     if (rc != CTR_OK) return rc;
     hipLaunchKernelGGL(mlp_fwd_kernel<NcfShape>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, (hipStream_t)stream,
                        b.d, x, ldx, m);
+  } else if (matches<NcfTowerShape, false>(layers, nlayers, b.d)) {
+    rc = allow_lds(mlp_fwd_kernel<NcfTowerShape>, b.lds_bytes);
+    if (rc != CTR_OK) return rc;
+    hipLaunchKernelGGL(mlp_fwd_kernel<NcfTowerShape>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes,
+                       (hipStream_t)stream, b.d, x, ldx, m);
   } else if (matches<DienAttShape, false>(layers, nlayers, b.d)) {
     rc = allow_lds(mlp_fwd_kernel<DienAttShape>, b.lds_bytes);
     if (rc != CTR_OK) return rc;
@@ -984,6 +997,7 @@ extern "C" int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp
                        m, gy, ldgy, gx, ldgx, workspace, b.slab);                                                  \
   } while (0)
   if (matches<NcfShape, true>(layers, nlayers, b.d)) CTR_LAUNCH_BWD(NcfShape, 14);
+  else if (matches<NcfTowerShape, true>(layers, nlayers, b.d)) CTR_LAUNCH_BWD(NcfTowerShape, 12);
   else if (matches<DienAttShape, true>(layers, nlayers, b.d)) {
     if (2 * b.lds_bytes <= 160 * 1024) {  // two resident workgroups per CU (the kernel is capped at 256 registers)
       grid = ctr_ceil_div(tiles, kWaves);

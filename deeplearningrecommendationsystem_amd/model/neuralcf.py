@@ -16,9 +16,16 @@ class _NeuralCFFunction(torch.autograd.Function):
     """inputs: user_idx, item_idx, err_flag, n_hidden, then parameters in the
     order GMF_U, GMF_I, MLP_U, MLP_I, (W,b) x n_hidden, linear W,b, linear2 W,b.
 
-    Buffer layout (one (B, L0 + 2*mf) matrix, no torch.cat anywhere):
-        [ MLP_U[u] | MLP_I[i] |  GMF_U[u]*GMF_I[i] | linear(h) ]
-          `-- MLP input x0 --'   `------ input of linear2 -----'
+    ``linear`` (h -> mf_dim, no activation) feeds only ``linear2`` (reference model/neuralcf.py:50-56), so
+    the pair is one k-wide dot product per sample: ``[gmf | linear(h)] . w2 + b2 == [gmf | h] . wfold + c``
+    with ``wfold = [w2[:mf] | W_l^T w2[mf:]]``, ``c = b_l . w2[mf:] + b2`` (ops.fold_head_fwd, O(mf*k) per
+    step).  The (B, mf_dim) output of ``linear`` and its gradient never exist; the gradients of
+    ``linear`` / ``linear2`` come back through the chain rule (ops.fold_head_bwd) from the k + mf sums the
+    head's backward produces anyway.  Same values up to fp32 rounding (parity tests unchanged).
+
+    Buffer layout (one (B, L0 + mf + k) matrix, no torch.cat anywhere):
+        [ MLP_U[u] | MLP_I[i] |  GMF_U[u]*GMF_I[i] | h = tower(x0) ]
+          `-- MLP input x0 --'   `--- input of the folded head ---'
     """
 
     @staticmethod
@@ -26,45 +33,64 @@ class _NeuralCFFunction(torch.autograd.Function):
         batch = user_idx.numel()
         mf, half = gmf_u.shape[1], mlp_u.shape[1]
         l0 = 2 * half
-        buf = torch.empty((batch, l0 + 2 * mf), dtype=torch.float32, device=gmf_u.device)
+        hidden = [Layer(dense[2 * k], dense[2 * k + 1], ACT_RELU) for k in range(n_hidden)]
+        proj_w, proj_b = dense[2 * n_hidden], dense[2 * n_hidden + 1]
+        head_w, head_b = dense[2 * n_hidden + 2], dense[2 * n_hidden + 3]
+        kh = proj_w.shape[1]  # width of h
+        buf = torch.empty((batch, l0 + mf + (kh if n_hidden else 0)), dtype=torch.float32, device=gmf_u.device)
         specs = _specs(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i)
         ops.embed_fwd(specs, None, batch, buf, err_flag)
-        hidden = [Layer(dense[2 * k], dense[2 * k + 1], ACT_RELU) for k in range(n_hidden)]
-        proj = Layer(dense[2 * n_hidden], dense[2 * n_hidden + 1], ACT_NONE)
-        head = Layer(dense[2 * n_hidden + 2], dense[2 * n_hidden + 3], ACT_SIGMOID)
-        acts = ops.mlp_fwd(buf[:, :l0], hidden + [proj], last_out=buf[:, l0 + mf:])
-        prob = ops.linear_fwd(buf[:, l0:], head.weight, head.bias, ACT_SIGMOID)
+        wfold, cfold = ops.fold_head_fwd(head_w, mf, proj_w, proj_b, head_b)
+        if n_hidden:
+            acts = ops.mlp_fwd(buf[:, :l0], hidden, last_out=buf[:, l0 + mf:])
+            prob = ops.linear_fwd(buf[:, l0:], wfold, cfold, ACT_SIGMOID)
+        else:
+            # no tower: h is x0 itself, which sits in FRONT of the GMF columns
+            acts = [buf[:, :l0]]
+            wf = torch.cat([wfold[:, mf:], wfold[:, :mf]], dim=1)
+            prob = ops.linear_fwd(buf, wf, cfold, ACT_SIGMOID)
         ctx.n_hidden = n_hidden
-        ctx.save_for_backward(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i, buf, prob, *acts[1:-1], *dense)
+        ctx.save_for_backward(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i, buf, prob, wfold, *acts[1:-1], *dense)
         return prob
 
     @staticmethod
     def backward(ctx, gprob):
         n_hidden = ctx.n_hidden
         saved = ctx.saved_tensors
-        user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i, buf, prob = saved[:8]
-        mids = list(saved[8:8 + n_hidden])
-        dense = saved[8 + n_hidden:]
+        user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i, buf, prob, wfold = saved[:9]
+        nmid = max(n_hidden - 1, 0)
+        mids = list(saved[9:9 + nmid])
+        dense = saved[9 + nmid:]
         batch = user_idx.numel()
         mf, l0 = gmf_u.shape[1], 2 * mlp_u.shape[1]
         hidden = [Layer(dense[2 * k], dense[2 * k + 1], ACT_RELU) for k in range(n_hidden)]
-        proj = Layer(dense[2 * n_hidden], dense[2 * n_hidden + 1], ACT_NONE)
-        head = Layer(dense[2 * n_hidden + 2], dense[2 * n_hidden + 3], ACT_SIGMOID)
+        proj_w, proj_b = dense[2 * n_hidden], dense[2 * n_hidden + 1]
+        head_w, head_b = dense[2 * n_hidden + 2], dense[2 * n_hidden + 3]
 
         tables = (gmf_u, gmf_i, mlp_u, mlp_i)
-        zeros = ops.zero_grads(list(tables) + list(dense))
+        cfold_like = head_b  # (1,)
+        zeros = ops.zero_grads(list(tables) + list(dense) + [wfold, cfold_like.new_empty(4)])
+        gwfold, gcfold = zeros[id(wfold)], list(zeros.values())[-1][:1]
         gbuf = torch.empty_like(buf)
-        g_head_w, g_head_b = zeros[id(head.weight)], zeros[id(head.bias)]
-        ops.linear_bwd(buf[:, l0:], head.weight, prob, gprob.contiguous(), ACT_SIGMOID, gbuf[:, l0:],
-                       g_head_w, g_head_b)
-        acts = [buf[:, :l0]] + mids + [buf[:, l0 + mf:]]
-        layer_grads, _ = ops.mlp_bwd(acts, hidden + [proj], gbuf[:, l0 + mf:], gbuf[:, :l0], zeros=zeros)
+        if n_hidden:
+            ops.linear_bwd(buf[:, l0:], wfold, prob, gprob.contiguous(), ACT_SIGMOID, gbuf[:, l0:], gwfold, gcfold)
+            acts = [buf[:, :l0]] + mids + [buf[:, l0 + mf:]]
+            layer_grads, _ = ops.mlp_bwd(acts, hidden, gbuf[:, l0 + mf:], gbuf[:, :l0], zeros=zeros)
+        else:
+            wf = torch.cat([wfold[:, mf:], wfold[:, :mf]], dim=1)
+            gwf = torch.zeros_like(wf)
+            ops.linear_bwd(buf, wf, prob, gprob.contiguous(), ACT_SIGMOID, gbuf, gwf, gcfold)
+            gwfold.copy_(torch.cat([gwf[:, l0:], gwf[:, :l0]], dim=1))
+            layer_grads = []
+        g_proj_w, g_proj_b = zeros[id(proj_w)], zeros[id(proj_b)]
+        g_head_w, g_head_b = zeros[id(head_w)], zeros[id(head_b)]
+        ops.fold_head_bwd(head_w, mf, proj_w, proj_b, gwfold, gcfold, g_head_w, g_proj_w, g_proj_b, g_head_b)
         tgrads = zeros
         ops.embed_bwd(_specs(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i), None, batch, gbuf, tgrads)
         out = [None, None, None, None] + [tgrads[id(t)] for t in tables]
         for gw, gb in layer_grads:
             out += [gw, gb]
-        out += [g_head_w, g_head_b]
+        out += [g_proj_w, g_proj_b, g_head_w, g_head_b]
         return tuple(out)
 
 

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -311,6 +311,29 @@ def zero_grads(tensors: Sequence[torch.Tensor]) -> dict:
         out[id(t)] = flat[off:off + t.numel()].view(t.shape)
         off += n
     return out
+
+
+def fold_head_fwd(u_full: torch.Tensor, p: int, w: torch.Tensor, b: Optional[torch.Tensor],
+                  b2: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(wfold (1, p+k), cfold (1,)) of the layer ``w, b`` (n x k) composed with the single-unit layer
+    ``u_full`` (1, p+n) whose first p columns pass through (ctr_fold_head_fwd)"""
+    n, k = w.shape
+    wfold = torch.empty((1, p + k), dtype=torch.float32, device=w.device)
+    cfold = torch.empty(1, dtype=torch.float32, device=w.device)
+    _lib.check(_lib.load().ctr_fold_head_fwd(u_full.data_ptr(), p, w.data_ptr(), _ld(w), _lib.ptr(b), _lib.ptr(b2), n, k,
+                                             wfold.data_ptr(), cfold.data_ptr(), _lib.stream_ptr()), "ctr_fold_head_fwd")
+    return wfold, cfold
+
+
+def fold_head_bwd(u_full: torch.Tensor, p: int, w: torch.Tensor, b: Optional[torch.Tensor], gwfold: torch.Tensor,
+                  gc: torch.Tensor, gu_full: Optional[torch.Tensor], gw: Optional[torch.Tensor],
+                  gb: Optional[torch.Tensor], gb2: Optional[torch.Tensor]) -> None:
+    """chain rule through ``fold_head_fwd``; every gradient is accumulated (ctr_fold_head_bwd)"""
+    n, k = w.shape
+    _lib.check(_lib.load().ctr_fold_head_bwd(u_full.data_ptr(), p, w.data_ptr(), _ld(w), _lib.ptr(b), n, k,
+                                             gwfold.data_ptr(), gc.data_ptr(), _lib.ptr(gu_full), _lib.ptr(gw),
+                                             _ld(gw) if gw is not None else 0, _lib.ptr(gb), _lib.ptr(gb2),
+                                             _lib.stream_ptr()), "ctr_fold_head_bwd")
 
 
 FUSED_MLP = True  # narrow stacks run as one launch (ctr_mlp_fwd/bwd) when their shape allows

@@ -318,6 +318,22 @@ int ctr_shard_bucket(const int64_t* ids, int64_t n, int world, int64_t* counts, 
                      int64_t* send, int64_t* perm, int64_t* inv, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Head folding: a linear layer W (n x k, bias b) whose output feeds ONLY a single-unit layer u is the
+ * k-wide dot product  (h W^T + b).u + b2 == h.v + c,  v = W^T u,  c = b.u + b2.  NeuralCF ends like
+ * that (model/neuralcf.py:27 linear, :50-56 cat + linear2): folding per step keeps the 8 -> mf_dim
+ * layer, its (B, mf_dim) output and that output's gradient out of the batch-sized work.
+ *   u_full = [ p columns that pass through (the GMF half of linear2.weight) | n columns fed by W ]
+ * fwd: wfold[0:p] = u_full[0:p], wfold[p:p+k] = W^T u, cfold[0] = b.u + b2[0]   (b, b2 may be null)
+ * bwd: from gwfold (p+k) = d/d wfold and gc[0] = d/d cfold, all outputs ACCUMULATED (nullable):
+ *      gu_full += [gwfold[0:p] | W gwfold[p:] + b gc],  gw += u (x) gwfold[p:],  gb += u gc,  gb2 += gc.
+ * ---------------------------------------------------------------------- */
+int ctr_fold_head_fwd(const float* u_full, int p, const float* w, int64_t ldw, const float* b, const float* b2, int n,
+                      int k, float* wfold, float* cfold, void* stream);
+int ctr_fold_head_bwd(const float* u_full, int p, const float* w, int64_t ldw, const float* b, int n, int k,
+                      const float* gwfold, const float* gc, float* gu_full, float* gw, int64_t ldgw, float* gb,
+                      float* gb2, void* stream);
+
+/* ------------------------------------------------------------------------
  * The rest of a train_loop body (trainer/trainer.py:37-39).
  * ---------------------------------------------------------------------- */
 

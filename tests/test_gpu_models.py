@@ -94,6 +94,18 @@ def test_neuralcf_config2_full_batch_against_oracle():
     _vs_oracle("neuralcf", NeuralCF(943, 1682, 64, [128, 64, 32, 16, 8]), [u, i], synth.labels(65536, True, gen))
 
 
+@pytest.mark.parametrize("layers", [[16], [16, 8], [32, 24, 12]])
+def test_neuralcf_other_towers_against_oracle(layers):
+    # the folded head (linear + linear2 as one dot product) with no tower, one hidden layer, and a stack
+    # whose widths are not the pinned BASELINE shape (generic fused kernel)
+    from deeplearningrecommendationsystem_amd import synth
+    from deeplearningrecommendationsystem_amd.model import NeuralCF
+    torch.manual_seed(4)
+    gen = synth.generator(14)
+    u, i = synth.id_batch(3000, 50, 60, gen=gen)
+    _vs_oracle("neuralcf", NeuralCF(50, 60, 12, layers), [u, i], synth.labels(3000, True, gen))
+
+
 def test_index_out_of_range_raises_like_nn_embedding():
     from deeplearningrecommendationsystem_amd.model import MatrixFactorization
     m = MatrixFactorization(5, 6, 4).to(DEV)

@@ -265,6 +265,29 @@ def test_linear_direct_to_lds_odd_leading_dimensions(ops):
     torch.testing.assert_close(gb.cpu(), gz.sum(0).float(), rtol=1e-5, atol=2e-6 * scale)
 
 
+def test_fold_head_matches_the_unfolded_pair(ops):
+    """(h W^T + b).u + b2 == h.v + c and its chain rule (ctr_fold_head_fwd/bwd) against autograd on the
+    unfolded expression"""
+    g = torch.Generator().manual_seed(5)
+    for p_, n, k in [(64, 64, 8), (0, 5, 3), (7, 130, 33)]:
+        u = torch.randn(1, p_ + n, generator=g).double().requires_grad_(True)
+        w = torch.randn(n, k, generator=g).double().requires_grad_(True)
+        b = torch.randn(n, generator=g).double().requires_grad_(True)
+        b2 = torch.randn(1, generator=g).double().requires_grad_(True)
+        wfold_ref = torch.cat([u[:, :p_], u[:, p_:] @ w], dim=1)
+        c_ref = (b * u[0, p_:]).sum() + b2[0]
+        du, dw, db, db2 = (t.detach().float().to(DEV) for t in (u, w, b, b2))
+        wfold, cfold = ops.fold_head_fwd(du, p_, dw, db, db2)
+        torch.testing.assert_close(wfold.cpu(), wfold_ref.detach().float(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(cfold.cpu(), c_ref.detach().float().reshape(1), rtol=1e-5, atol=1e-6)
+        gwf, gc = torch.randn(1, p_ + k, generator=g), torch.randn(1, generator=g)
+        ((wfold_ref * gwf.double()).sum() + c_ref * gc.double()[0]).backward()
+        gu, gw, gb, gb2 = (torch.ones_like(t) for t in (du, dw, db, db2))  # accumulated into
+        ops.fold_head_bwd(du, p_, dw, db, gwf.to(DEV), gc.to(DEV), gu, gw, gb, gb2)
+        for got, ref in ((gu, u), (gw, w), (gb, b), (gb2, b2)):
+            torch.testing.assert_close(got.cpu(), 1.0 + ref.grad.float(), rtol=1e-5, atol=1e-5)
+
+
 def test_mf_fused_kernels(ops):
     g = torch.Generator().manual_seed(3)
     for dim, batch in [(64, 1024), (12, 37), (5, 3)]:
