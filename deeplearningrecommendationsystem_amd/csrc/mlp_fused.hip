@@ -59,6 +59,16 @@ struct StackDesc {
   int db_off[kMaxLayers];  // bwd: first bias-gradient slot of each layer
 };
 
+// Optional single-unit head on top of the stack (ctr_mlp_head_fwd): out[row] = act(x_extra[row,:p] . w[:p] +
+// y_last[row,:] . w[p:] + c[0]) formed in the tile epilogue, while the last activations are still in LDS.
+struct HeadDesc {
+  const float* x; int64_t ldx; int p;  // p extra input columns (multiple of 8, <= 64), 16-byte aligned rows
+  const float* w;                       // p + n_last weights
+  const float* c;                       // one bias
+  float* out; int64_t ldout; int act;
+};
+constexpr int kHeadMax = 192;           // p + n_last
+
 // Shape policy.  DynShape: every width comes from the descriptor at run time.  A fixed shape
 // pins n / k / activation of every layer at compile time for a stack that matters (the
 // BASELINE NeuralCF tower): the layer loops unroll, the index divisions, tail chunks and
@@ -353,9 +363,9 @@ __device__ __forceinline__ void fwd_chunk(const float* xt, int xstride, const fl
   }
 }
 
-template <class S>
+template <class S, bool HEAD = false>
 __global__ void __launch_bounds__(kThreads, S::kWavesPerSimd)
-mlp_fwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int64_t m) {
+mlp_fwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int64_t m, const HeadDesc hd) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   // layer descriptors are read inside the per-tile layer loop: from LDS, not from the
   // kernarg segment (320 scalar loads + waits per wave otherwise, ~40 % of the run time)
@@ -374,6 +384,13 @@ mlp_fwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
   float* ta = lds + wfloats + wave * 32 * (sa + sb);
   float* tb = ta + 32 * sa;
   const int r = lane & 31, h = lane >> 5;
+  __shared__ float s_hw[HEAD ? kHeadMax : 1];
+  float hc = 0.0f;
+  const int nlast = S::kFixed ? S::N[S::kFixed ? S::kLayers - 1 : 0] : d.l[nlayers - 1].n;
+  if constexpr (HEAD) {
+    for (int i = threadIdx.x; i < hd.p + nlast; i += blockDim.x) s_hw[i] = hd.w[i];
+    hc = hd.c[0];
+  }
   stage_weights(s_w, d, true);
   __syncthreads();
 
@@ -409,6 +426,17 @@ mlp_fwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
       }
     }
     fetch(tile + tstride);
+    // head: this row's extra input columns, requested now and used after the last layer
+    // (lane (r, h) takes the 4-float chunks 2u + h of row r)
+    float4 xe[HEAD ? 8 : 1];
+    if constexpr (HEAD) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = 8 * u + 4 * h;
+        xe[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < hd.p && row0 + r < m) xe[u] = *reinterpret_cast<const float4*>(hd.x + (row0 + r) * hd.ldx + c);
+      }
+    }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int li = 0; li < nlayers; ++li) {
@@ -453,6 +481,26 @@ mlp_fwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
           }
         }
       }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if constexpr (HEAD) {
+      // the last layer left its output in the tile it wrote: row r, columns split between the two half-waves
+      const float* fin = ((nlayers - 1) & 1) ? ta : tb;
+      const int fs = ((nlayers - 1) & 1) ? sa : sb;
+      float acc = 0.0f;
+      for (int j = h; j < nlast; j += 2) acc = fmaf(fin[r * fs + j], s_hw[hd.p + j], acc);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = 8 * u + 4 * h;
+        if (c < hd.p) {
+          acc = fmaf(xe[u].x, s_hw[c], acc);
+          acc = fmaf(xe[u].y, s_hw[c + 1], acc);
+          acc = fmaf(xe[u].z, s_hw[c + 2], acc);
+          acc = fmaf(xe[u].w, s_hw[c + 3], acc);
+        }
+      }
+      acc += __shfl_xor(acc, 32, 64);
+      if (h == 0 && row0 + r < m) hd.out[(row0 + r) * hd.ldout] = ctr_act(acc + hc, hd.act);
       __builtin_amdgcn_wave_barrier();
     }
   }
@@ -931,8 +979,8 @@ int allow_lds(K kernel, size_t bytes) {
 
 }  // namespace
 
-extern "C" int ctr_mlp_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
-                           void* stream) {
+static int mlp_fwd_impl(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
+                        const ctr_mlp_head_t* head, void* stream) {
   CTR_REQUIRE(m >= 0, CTR_EINVAL);
   if (m == 0) return CTR_OK;
   CTR_REQUIRE(x && ctr_aligned16(x) && ldx % 4 == 0, CTR_EALIGN);
@@ -943,16 +991,37 @@ extern "C" int ctr_mlp_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp
   const int64_t tiles = ctr_ceil_div(m, 32);
   int64_t grid = ctr_ceil_div(tiles, kWaves);
   if (grid > 256) grid = 256;  // persistent: one workgroup per CU, weights staged once
+  HeadDesc hd{nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0};
+  hipStream_t st = (hipStream_t)stream;
+  if (head) {
+    CTR_REQUIRE(head->w && head->c && head->out && head->p >= 0 && head->ldout >= 1, CTR_EINVAL);
+    CTR_REQUIRE(head->act >= CTR_ACT_NONE && head->act <= CTR_ACT_SIGMOID, CTR_EINVAL);
+    CTR_REQUIRE(head->p == 0 || (head->x && head->ldx >= head->p), CTR_EINVAL);
+    CTR_REQUIRE(head->p <= 64 && head->p % 8 == 0 && head->p + layers[nlayers - 1].n <= kHeadMax, CTR_ELIMIT);
+    CTR_REQUIRE(head->p == 0 || (ctr_aligned16(head->x) && head->ldx % 4 == 0), CTR_EALIGN);
+    hd = HeadDesc{head->x, head->ldx, head->p, head->w, head->c, head->out, head->ldout, head->act};
+    if (matches<NcfTowerShape, false>(layers, nlayers, b.d)) {
+      rc = allow_lds(mlp_fwd_kernel<NcfTowerShape, true>, b.lds_bytes);
+      if (rc != CTR_OK) return rc;
+      hipLaunchKernelGGL((mlp_fwd_kernel<NcfTowerShape, true>), dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, st, b.d,
+                         x, ldx, m, hd);
+    } else {
+      rc = allow_lds(mlp_fwd_kernel<DynShape, true>, b.lds_bytes);
+      if (rc != CTR_OK) return rc;
+      hipLaunchKernelGGL((mlp_fwd_kernel<DynShape, true>), dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, st, b.d, x,
+                         ldx, m, hd);
+    }
+    return ctr_launch_status();
+  }
   if (matches<NcfShape, false>(layers, nlayers, b.d)) {
     rc = allow_lds(mlp_fwd_kernel<NcfShape>, b.lds_bytes);
     if (rc != CTR_OK) return rc;
-    hipLaunchKernelGGL(mlp_fwd_kernel<NcfShape>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, (hipStream_t)stream,
-                       b.d, x, ldx, m);
+    hipLaunchKernelGGL(mlp_fwd_kernel<NcfShape>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, st, b.d, x, ldx, m, hd);
   } else if (matches<NcfTowerShape, false>(layers, nlayers, b.d)) {
     rc = allow_lds(mlp_fwd_kernel<NcfTowerShape>, b.lds_bytes);
     if (rc != CTR_OK) return rc;
-    hipLaunchKernelGGL(mlp_fwd_kernel<NcfTowerShape>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes,
-                       (hipStream_t)stream, b.d, x, ldx, m);
+    hipLaunchKernelGGL(mlp_fwd_kernel<NcfTowerShape>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, st, b.d, x, ldx, m,
+                       hd);
   } else if (matches<DienAttShape, false>(layers, nlayers, b.d)) {
     rc = allow_lds(mlp_fwd_kernel<DienAttShape>, b.lds_bytes);
     if (rc != CTR_OK) return rc;
@@ -960,15 +1029,25 @@ extern "C" int ctr_mlp_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp
       grid = ctr_ceil_div(tiles, kWaves);
       if (grid > 512) grid = 512;
     }
-    hipLaunchKernelGGL(mlp_fwd_kernel<DienAttShape>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes,
-                       (hipStream_t)stream, b.d, x, ldx, m);
+    hipLaunchKernelGGL(mlp_fwd_kernel<DienAttShape>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, st, b.d, x, ldx, m,
+                       hd);
   } else {
     rc = allow_lds(mlp_fwd_kernel<DynShape>, b.lds_bytes);
     if (rc != CTR_OK) return rc;
-    hipLaunchKernelGGL(mlp_fwd_kernel<DynShape>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, (hipStream_t)stream,
-                       b.d, x, ldx, m);
+    hipLaunchKernelGGL(mlp_fwd_kernel<DynShape>, dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, st, b.d, x, ldx, m, hd);
   }
   return ctr_launch_status();
+}
+
+extern "C" int ctr_mlp_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
+                           void* stream) {
+  return mlp_fwd_impl(x, ldx, m, layers, nlayers, nullptr, stream);
+}
+
+extern "C" int ctr_mlp_head_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
+                                const ctr_mlp_head_t* head, void* stream) {
+  CTR_REQUIRE(head != nullptr, CTR_EINVAL);
+  return mlp_fwd_impl(x, ldx, m, layers, nlayers, head, stream);
 }
 
 extern "C" int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,

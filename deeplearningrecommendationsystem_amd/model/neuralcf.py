@@ -42,8 +42,11 @@ class _NeuralCFFunction(torch.autograd.Function):
         ops.embed_fwd(specs, None, batch, buf, err_flag)
         wfold, cfold = ops.fold_head_fwd(head_w, mf, proj_w, proj_b, head_b)
         if n_hidden:
-            acts = ops.mlp_fwd(buf[:, :l0], hidden, last_out=buf[:, l0 + mf:])
-            prob = ops.linear_fwd(buf[:, l0:], wfold, cfold, ACT_SIGMOID)
+            # tower + folded head in one launch: the head's dot product runs on the tile's last
+            # activations while they are still in LDS
+            head = ops.Head(buf[:, l0:l0 + mf], wfold, cfold, ACT_SIGMOID)
+            acts = ops.mlp_fwd(buf[:, :l0], hidden, last_out=buf[:, l0 + mf:], head=head)
+            prob = head.out
         else:
             # no tower: h is x0 itself, which sits in FRONT of the GMF columns
             acts = [buf[:, :l0]]

@@ -362,8 +362,21 @@ def _fusable(x, layers) -> bool:
     return x.shape[0] >= 1024
 
 
-def mlp_fwd(x: torch.Tensor, layers: Sequence[Layer], last_out: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
-    """returns [x, y_1, ..., y_n]; the last layer may write into ``last_out``"""
+class Head:
+    """single-unit layer on [x_extra | last activations] formed in the fused stack's epilogue
+    (``ctr_mlp_head_t``): ``out = act(x_extra . w[:p] + y_last . w[p:] + c)``"""
+
+    def __init__(self, x_extra: Optional[torch.Tensor], w: torch.Tensor, c: torch.Tensor, act: int):
+        self.x_extra, self.w, self.c, self.act = x_extra, w, c, act
+        self.out: Optional[torch.Tensor] = None  # (m, 1), set by mlp_fwd
+
+
+def mlp_fwd(x: torch.Tensor, layers: Sequence[Layer], last_out: Optional[torch.Tensor] = None,
+            head: Optional[Head] = None) -> List[torch.Tensor]:
+    """returns [x, y_1, ..., y_n]; the last layer may write into ``last_out``.  With ``head`` the
+    single-unit layer on top is computed too and left in ``head.out`` (in the same launch when the
+    stack runs fused, else by ``linear_fwd`` on the concatenation-free operand, which then must be
+    the columns right in front of ``last_out``)."""
     x = _mat(x, "x")
     m = x.shape[0]
     if _fusable(x, layers):
@@ -372,11 +385,27 @@ def mlp_fwd(x: torch.Tensor, layers: Sequence[Layer], last_out: Optional[torch.T
                   torch.empty((m, layers[-1].weight.shape[0]), dtype=torch.float32, device=x.device))
         arr = _mlp_layer_array(layers, ys)
         dims = [(layer.weight.shape[0], layer.weight.shape[1]) for layer in layers]
+        lib = _lib.load()
+        if head is not None:
+            p = 0 if head.x_extra is None else head.x_extra.shape[1]
+            out = torch.empty((m, 1), dtype=torch.float32, device=x.device)
+            hd = _lib.MlpHead(_lib.ptr(head.x_extra), _ld(head.x_extra) if p else 0, head.w.data_ptr(),
+                              head.c.data_ptr(), out.data_ptr(), 1, p, head.act)
+            rc = _timed("mlp_fused_fwd", lambda: (4 * m * (dims[0][1] + p + 1 + sum(n for n, _ in dims)),
+                                                  2 * m * (sum(n * k for n, k in dims) + p + dims[-1][0])),
+                        lib.ctr_mlp_head_fwd, x.data_ptr(), _ld(x), m, arr, len(layers), C.byref(hd), _lib.stream_ptr())
+            if rc not in _REFUSED:
+                _lib.check(rc, "ctr_mlp_head_fwd")
+                head.out = out
+                return [x] + ys
+            if _profiler is not None and _profiler.records and _profiler.records[-1][0] == "mlp_fused_fwd":
+                _profiler.records.pop()  # refused: nothing ran
         rc = _timed("mlp_fused_fwd", lambda: (4 * m * (dims[0][1] + sum(n for n, _ in dims)),
                                               2 * m * sum(n * k for n, k in dims)),
-                    _lib.load().ctr_mlp_fwd, x.data_ptr(), _ld(x), m, arr, len(layers), _lib.stream_ptr())
+                    lib.ctr_mlp_fwd, x.data_ptr(), _ld(x), m, arr, len(layers), _lib.stream_ptr())
         if rc not in _REFUSED:
             _lib.check(rc, "ctr_mlp_fwd")
+            _head_unfused(head, ys[-1])
             return [x] + ys
         if _profiler is not None and _profiler.records and _profiler.records[-1][0] == "mlp_fused_fwd":
             _profiler.records.pop()  # refused: nothing ran
@@ -384,7 +413,23 @@ def mlp_fwd(x: torch.Tensor, layers: Sequence[Layer], last_out: Optional[torch.T
     for k, layer in enumerate(layers):
         out = last_out if (k == len(layers) - 1) else None
         acts.append(linear_fwd(acts[-1], layer.weight, layer.bias, layer.act, out=out))
+    _head_unfused(head, acts[-1])
     return acts
+
+
+def _head_unfused(head: Optional[Head], y_last: torch.Tensor) -> None:
+    if head is None:
+        return
+    if head.x_extra is None:
+        operand = y_last
+    else:
+        # [x_extra | y_last] must already be adjacent columns of one buffer (no torch.cat on the hot path)
+        p, n = head.x_extra.shape[1], y_last.shape[1]
+        adjacent = (head.x_extra.stride(0) == y_last.stride(0) and
+                    head.x_extra.data_ptr() + 4 * p == y_last.data_ptr())
+        operand = (torch.as_strided(head.x_extra, (head.x_extra.shape[0], p + n), (head.x_extra.stride(0), 1))
+                   if adjacent else torch.cat([head.x_extra, y_last], dim=1))
+    head.out = linear_fwd(operand, head.w, head.c, head.act)
 
 
 def mlp_bwd(acts: Sequence[torch.Tensor], layers: Sequence[Layer], gy: torch.Tensor,

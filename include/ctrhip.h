@@ -299,6 +299,22 @@ typedef struct ctr_mlp_layer {
 /* y_0 = act_0(x W_0^T + b_0), y_i = act_i(y_{i-1} W_i^T + b_i); layers: host array */
 int ctr_mlp_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
                 void* stream);
+/* The same stack with a single-unit head formed in its epilogue, while the last activations are still
+ * on chip:  out[row*ldout] = act( x_extra[row, 0:p] . w[0:p] + y_last[row, :] . w[p:] + c[0] ).
+ * NeuralCF's folded linear2 (see ctr_fold_head_fwd): x_extra = the GMF product, w = wfold, c = cfold.
+ * The stack's own outputs are written as by ctr_mlp_fwd.  Limits: p <= 64 and a multiple of 8, x_extra
+ * rows 16-byte aligned (else CTR_ELIMIT / CTR_EALIGN, nothing enqueued). */
+typedef struct ctr_mlp_head {
+  const float* x;   /* (m, ldx): p extra input columns, or NULL when p == 0 */
+  int64_t ldx;
+  const float* w;   /* p + n_last weights */
+  const float* c;   /* one bias (device) */
+  float* out;       /* (m) at stride ldout */
+  int64_t ldout;
+  int32_t p, act;
+} ctr_mlp_head_t;
+int ctr_mlp_head_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
+                     const ctr_mlp_head_t* head, void* stream);
 /* gy: gradient of the LAST layer's output; gx (nullable): gradient of x.  workspace is
  * required: (number of workgroups <= 256) * sum_i (n_i*k_i + n_i) floats. */
 int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,

@@ -49,6 +49,8 @@ def test_field_struct_matches_header_size(lib):
     assert ctypes.sizeof(lib.Field) == 96
     # 3 pointers + int64 + 2 pointers + 4 int32 = 64 bytes, as ctr_mlp_layer_t
     assert ctypes.sizeof(lib.MlpLayer) == 64
+    # pointer + int64 + 3 pointers + int64 + 2 int32 = 56 bytes, as ctr_mlp_head_t
+    assert ctypes.sizeof(lib.MlpHead) == 56
 
 
 def test_strerror(lib):
@@ -100,6 +102,8 @@ def _parse_header_prototypes():
                     kinds.append("field*")
                 elif "ctr_mlp_layer_t" in a:
                     kinds.append("mlp*")
+                elif "ctr_mlp_head_t" in a:
+                    kinds.append("head*")
                 elif "ctr_adam_tensor_t" in a:
                     kinds.append("adam*")
                 elif a.startswith("float "):
@@ -135,6 +139,8 @@ def test_ctypes_signatures_match_header_prototypes(lib):
                 got.append("field*")
             elif a is ctypes.POINTER(lib.MlpLayer):
                 got.append("mlp*")
+            elif a is ctypes.POINTER(lib.MlpHead):
+                got.append("head*")
             elif a is ctypes.POINTER(lib.AdamTensor):
                 got.append("adam*")
             elif a is ctypes.c_float:

@@ -265,6 +265,31 @@ def test_linear_direct_to_lds_odd_leading_dimensions(ops):
     torch.testing.assert_close(gb.cpu(), gz.sum(0).float(), rtol=1e-5, atol=2e-6 * scale)
 
 
+@pytest.mark.parametrize("dims,p", [([128, 64, 32, 16, 8], 64), ([16, 8], 8), ([24, 16, 8], 0), ([32, 16], 40)])
+def test_mlp_forward_with_fused_head(ops, dims, p):
+    """ctr_mlp_head_fwd: the single-unit layer on [x_extra | last activations] from the stack's epilogue
+    (pinned NeuralCF tower, generic stacks, no extra columns, ragged batch)"""
+    g = torch.Generator().manual_seed(sum(dims) + p)
+    m = 1000 + p
+    buf = torch.randn(m, dims[0] + p + dims[-1] + 4, generator=g)  # [x0 | x_extra | room for y_last | pad]
+    layers = [ops.Layer((torch.randn(n, k, generator=g) / k ** 0.5).to(DEV), (torch.randn(n, generator=g) * 0.1).to(DEV), 1)
+              for k, n in zip(dims[:-1], dims[1:])]
+    w = torch.randn(1, p + dims[-1], generator=g)
+    c = torch.randn(1, generator=g)
+    dbuf = buf.to(DEV)
+    x0, xe = dbuf[:, :dims[0]], (dbuf[:, dims[0]:dims[0] + p] if p else None)
+    head = ops.Head(xe, w.to(DEV), c.to(DEV), 2)
+    acts = ops.mlp_fwd(x0, layers, last_out=dbuf[:, dims[0] + p:dims[0] + p + dims[-1]], head=head)
+    h = buf[:, :dims[0]].double()
+    for layer in layers:
+        h = torch.relu(h @ layer.weight.cpu().double().T + layer.bias.cpu().double())
+    torch.testing.assert_close(acts[-1].cpu(), h.float(), rtol=1e-5, atol=2e-6)
+    operand = torch.cat([buf[:, dims[0]:dims[0] + p].double(), h], dim=1)
+    ref = torch.sigmoid(operand @ w.double().T + c.double())
+    assert head.out.shape == (m, 1)
+    torch.testing.assert_close(head.out.cpu(), ref.float(), rtol=1e-5, atol=2e-6)
+
+
 def test_fold_head_matches_the_unfolded_pair(ops):
     """(h W^T + b).u + b2 == h.v + c and its chain rule (ctr_fold_head_fwd/bwd) against autograd on the
     unfolded expression"""
