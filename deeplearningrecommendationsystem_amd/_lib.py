@@ -15,7 +15,7 @@ import torch  # noqa: F401  (maps libamdhip64 first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTRHIP_LIB", os.path.join(_HERE, "libctrhip.so"))  # env override: A/B builds
-ABI_VERSION = 10
+ABI_VERSION = 11
 DIN_TRIPLE, DIN_PAIR = 0, 1  # layouts of the DIN attention operand (include/ctrhip.h)
 
 CTR_MAX_FIELDS = 32
@@ -39,6 +39,13 @@ class MlpHead(C.Structure):
     """mirror of ``ctr_mlp_head_t``"""
     _fields_ = [("x", C.c_void_p), ("ldx", C.c_int64), ("w", C.c_void_p), ("c", C.c_void_p), ("out", C.c_void_p),
                 ("ldout", C.c_int64), ("p", C.c_int32), ("act", C.c_int32)]
+
+
+class MlpHeadGrad(C.Structure):
+    """mirror of ``ctr_mlp_head_grad_t``"""
+    _fields_ = [("prob", C.c_void_p), ("ldprob", C.c_int64), ("gprob", C.c_void_p), ("ldgprob", C.c_int64),
+                ("x", C.c_void_p), ("ldx", C.c_int64), ("w", C.c_void_p), ("gx", C.c_void_p), ("ldgx", C.c_int64),
+                ("gw", C.c_void_p), ("gc", C.c_void_p), ("p", C.c_int32), ("act", C.c_int32)]
 
 
 class MlpLayer(C.Structure):
@@ -91,6 +98,7 @@ SIGNATURES = {
     "ctr_gru_bwd": (_i, [_p, _l, _p, _p, _p, _l, _i, _i, _p, _l, _p, _p, _p]),
     "ctr_mlp_fwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, _p]),
     "ctr_mlp_head_fwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, C.POINTER(MlpHead), _p]),
+    "ctr_mlp_head_bwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, C.POINTER(MlpHeadGrad), _p, _l, _p, _l, _p]),
     "ctr_mlp_bwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, _p, _l, _p, _l, _p, _l, _p]),
     "ctr_shard_bucket": (_i, [_p, _l, _i, _p, _p, _p, _p, _p, _p]),
     "ctr_fold_head_fwd": (_i, [_p, _i, _p, _l, _p, _p, _i, _i, _p, _p, _p]),

@@ -122,24 +122,8 @@ embed_fwd_kernel(const FieldPack P, int nfields, const float* __restrict__ x, in
         // the selected row bit-exactly, as the reference's matmul does
         const float* xr = x + (int64_t)b * ldx + f.src_col;
         v = Vec<VEC>::zero();
-        {
-          // four bag rows requested at a time (a load-use loop over single rows pays one L2 round trip per
-          // row); the FMAs stay in row order
-          int j = 0;
-          for (; j + 4 <= f.bag_size; j += 4) {
-            float w[4];
-            V t[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              w[q] = xr[j + q];
-              t[q] = ctr_ldg(reinterpret_cast<const V*>(f.table + (int64_t)(j + q) * f.width + off));
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v = vfma(w[q], t[q], v);
-          }
-          for (; j < f.bag_size; ++j)
-            v = vfma(xr[j], ctr_ldg(reinterpret_cast<const V*>(f.table + (int64_t)j * f.width + off)), v);
-        }
+        for (int j = 0; j < f.bag_size; ++j)
+          v = vfma(xr[j], ctr_ldg(reinterpret_cast<const V*>(f.table + (int64_t)j * f.width + off)), v);
       } break;
       case CTR_FIELD_DENSE: {
         v = *reinterpret_cast<const V*>(x + (int64_t)b * ldx + f.src_col + off);
@@ -492,10 +476,10 @@ extern "C" int ctr_embed_bwd(const ctr_field_t* fields, int nfields, const float
   const size_t dyn = (size_t)(plan.bag_floats + hot_floats) * sizeof(float);
   float* ws = slabs ? workspace : nullptr;
   if (plan.vec == 4)
-    hipLaunchKernelGGL(embed_bwd_kernel<4>, dim3(grid), dim3(kBlock), 0, st, plan.pack, nfields, x, ldx,
+    hipLaunchKernelGGL(embed_bwd_kernel<4>, dim3(grid), dim3(kBlock), dyn, st, plan.pack, nfields, x, ldx,
                        (uint32_t)batch, gout, ldo, plan.bag_floats, hot_floats, div, ws);
   else
-    hipLaunchKernelGGL(embed_bwd_kernel<1>, dim3(grid), dim3(kBlock), 0, st, plan.pack, nfields, x, ldx,
+    hipLaunchKernelGGL(embed_bwd_kernel<1>, dim3(grid), dim3(kBlock), dyn, st, plan.pack, nfields, x, ldx,
                        (uint32_t)batch, gout, ldo, plan.bag_floats, hot_floats, div, ws);
   rc = ctr_launch_status();
   if (rc != CTR_OK || !slabs) return rc;

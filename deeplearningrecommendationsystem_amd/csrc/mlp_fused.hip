@@ -69,6 +69,31 @@ struct HeadDesc {
 };
 constexpr int kHeadMax = 192;           // p + n_last
 
+// Backward of that head inside the stack's backward (ctr_mlp_head_bwd, pinned NeuralCF tower only: p = 64
+// extra columns, 8 last activations): per row gz = gprob * act'(prob); the tower's gY tile is gz * w[p:],
+// the extra columns' gradient gz * w[:p] is stored, and the p + 8 + 1 sums over the batch
+// (sum gz*x_extra, sum gz*y_last, sum gz) ride along to the slab.
+struct HeadBwdDesc {
+  const float* gprob; int64_t ldgp;
+  const float* prob; int64_t ldp;
+  const float* xe; int64_t ldxe;
+  const float* w;
+  float* gxe; int64_t ldgxe;
+  int act;
+};
+constexpr int kHeadBwdP = 64, kHeadBwdN = 8, kHeadBwdSums = kHeadBwdP + kHeadBwdN + 1;
+
+// one stage of the transposed reduction: lanes r and r ^ S exchange half of their N = 2*S' values
+template <int KEEP>
+__device__ __forceinline__ void xpose_stage(float* pr, int bit, int xr) {
+#pragma unroll
+  for (int i = 0; i < KEEP; ++i) {
+    const float send = bit ? pr[i] : pr[i + KEEP];
+    const float keep = bit ? pr[i + KEEP] : pr[i];
+    pr[i] = keep + __shfl_xor(send, xr, 64);
+  }
+}
+
 // Shape policy.  DynShape: every width comes from the descriptor at run time.  A fixed shape
 // pins n / k / activation of every layer at compile time for a stack that matters (the
 // BASELINE NeuralCF tower): the layer loops unroll, the index divisions, tail chunks and
@@ -533,10 +558,11 @@ __device__ __forceinline__ void dx_chunk(const float* gt, int gstride, const flo
   }
 }
 
-template <class S, int MAXT>
+template <class S, int MAXT, bool HEADB = false>
 __global__ void __launch_bounds__(kThreads, S::kWavesPerSimd)
 mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int64_t m, const float* __restrict__ gy,
-               int64_t ldgy, float* __restrict__ gx, int64_t ldgx, float* __restrict__ ws, int64_t slab) {
+               int64_t ldgy, float* __restrict__ gx, int64_t ldgx, float* __restrict__ ws, int64_t slab,
+               const HeadBwdDesc hb) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ StackDesc s_desc;  // see mlp_fwd_kernel
 #ifdef CTR_MLP_TIMING
@@ -574,6 +600,13 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
   // bias-gradient partials: nsum floats per wave in LDS (lane j owns column j of each layer)
   float* s_db = lds + wfloats + kWaves * 32 * (sa + sb) + wave * nsum;
   for (int i = lane0; i < nsum; i += 64) s_db[i] = 0.0f;
+  // fused head backward: its weights, and this lane's share of the batch sums
+  __shared__ __attribute__((aligned(16))) float s_hwb[HEADB ? kHeadBwdP + kHeadBwdN : 4];
+  float hx_sum[2] = {0.0f, 0.0f}, hy_sum = 0.0f, hc_sum = 0.0f;
+  if constexpr (HEADB) {
+    for (int i = threadIdx.x; i < kHeadBwdP + kHeadBwdN; i += blockDim.x) s_hwb[i] = hb.w[i];
+    __syncthreads();
+  }
 
   const int64_t tiles = (m + 31) / 32;
   const int nlayers = S::kFixed ? S::kLayers : d.nlayers;
@@ -584,7 +617,7 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
   const int64_t tstride = (int64_t)gridDim.x * kWaves;
   float4 pre[16];   // kPre: the next layer-input tile, in flight
   float4 gpre[16];  // kPre: the next tile's gY
-  const bool gvec = kPre && nl % 4 == 0 && ldgy % 4 == 0 && (reinterpret_cast<uintptr_t>(gy) & 15) == 0;
+  const bool gvec = !HEADB && kPre && nl % 4 == 0 && ldgy % 4 == 0 && (reinterpret_cast<uintptr_t>(gy) & 15) == 0;
   const float* xlast = last > 0 ? d.l[last > 0 ? last - 1 : 0].y : x;
   const int64_t ldxlast = last > 0 ? d.l[last > 0 ? last - 1 : 0].ldy : ldx;
   if constexpr (kPre) {
@@ -604,8 +637,55 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
     const int r = lane & 31, h = lane >> 5;
     // gradient of the last layer's output -> P (requested during the previous tile's
     // layer 0 when it can be fetched as dwordx4)
-    if (kPre && gvec) pre_commit<true>(gpre, tp, sa, nl, div_last, lane);
-    else tile_load1<8, S::kFixed>(tp, sa, gy, ldgy, row0, m, nl, div_last, lane);
+    if constexpr (HEADB) {
+      // lane (r, h): row r of the tile.  gz, the tower's gY tile (4 of its 8 columns per half-wave), the
+      // gradient of the extra columns (32 per half-wave), and the batch sums by a transposed reduction:
+      // lane r ends up with column (r & 15) of each 16-column group, summed over the 32 rows
+      const int64_t row = row0 + r;
+      const bool ok = row < m;
+      float gz = 0.0f;
+      if (ok) gz = hb.gprob[row * hb.ldgp] * ctr_act_grad(hb.prob[row * hb.ldp], hb.act);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tp[r * sa + 4 * h + q] = gz * s_hwb[kHeadBwdP + 4 * h + q];
+      if (h == 0) hc_sum += gz;
+      {
+        float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) yv = *reinterpret_cast<const float4*>(d.l[last].y + row * d.l[last].ldy + 4 * h);
+        float pr[4] = {gz * yv.x, gz * yv.y, gz * yv.z, gz * yv.w};
+        xpose_stage<2>(pr, r & 2, 2);
+        xpose_stage<1>(pr, r & 1, 1);
+        float t = pr[0];
+        t += __shfl_xor(t, 4, 64);
+        t += __shfl_xor(t, 8, 64);
+        t += __shfl_xor(t, 16, 64);
+        hy_sum += t;  // column 4h + (r & 3)
+      }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int c0 = 32 * h + 16 * half;
+        float pr[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 wv = *reinterpret_cast<const float4*>(s_hwb + c0 + 4 * i);
+          if (ok) {
+            xv = *reinterpret_cast<const float4*>(hb.xe + row * hb.ldxe + c0 + 4 * i);
+            *reinterpret_cast<float4*>(hb.gxe + row * hb.ldgxe + c0 + 4 * i) =
+                make_float4(gz * wv.x, gz * wv.y, gz * wv.z, gz * wv.w);
+          }
+          pr[4 * i + 0] = gz * xv.x; pr[4 * i + 1] = gz * xv.y; pr[4 * i + 2] = gz * xv.z; pr[4 * i + 3] = gz * xv.w;
+        }
+        xpose_stage<8>(pr, r & 8, 8);
+        xpose_stage<4>(pr, r & 4, 4);
+        xpose_stage<2>(pr, r & 2, 2);
+        xpose_stage<1>(pr, r & 1, 1);
+        hx_sum[half] += pr[0] + __shfl_xor(pr[0], 16, 64);  // column c0 + (r & 15)
+      }
+    } else if (kPre && gvec) {
+      pre_commit<true>(gpre, tp, sa, nl, div_last, lane);
+    } else {
+      tile_load1<8, S::kFixed>(tp, sa, gy, ldgy, row0, m, nl, div_last, lane);
+    }
     __builtin_amdgcn_wave_barrier();
     {
       // gZ = gY * act'(Y) of the last layer, in place (rows past m stay zero)
@@ -861,6 +941,23 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
   } else {
     for (int li = 0; li < nlayers; ++li) flush(li);
   }
+  if constexpr (HEADB) {
+    // the head's sums: every wave parks its share, the workgroup adds the four in wave order
+    float* s_h = s_red;  // [kWaves][80]; the flush above ended with a barrier
+    if (r < 16) {
+      s_h[wave * 80 + 32 * h + r] = hx_sum[0];
+      s_h[wave * 80 + 32 * h + 16 + r] = hx_sum[1];
+    }
+    if (r < 4) s_h[wave * 80 + kHeadBwdP + 4 * h + r] = hy_sum;
+    const float c = ctr_wave_sum(hc_sum);
+    if (lane == 0) s_h[wave * 80 + kHeadBwdP + kHeadBwdN] = c;
+    __syncthreads();
+    for (int i = threadIdx.x; i < kHeadBwdSums; i += blockDim.x) {
+      float v = s_h[i];
+      for (int w2 = 1; w2 < kWaves; ++w2) v += s_h[w2 * 80 + i];
+      ws[(int64_t)blockIdx.x * slab + off + i] = v;
+    }
+  }
   CTR_STAMP();
 #ifdef CTR_MLP_TIMING
   if (threadIdx.x == 0)
@@ -1073,7 +1170,7 @@ extern "C" int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp
     rc = allow_lds(mlp_bwd_kernel<S, T>, b.lds_bytes);                                                             \
     if (rc != CTR_OK) return rc;                                                                                   \
     hipLaunchKernelGGL((mlp_bwd_kernel<S, T>), dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, st, b.d, x, ldx, \
-                       m, gy, ldgy, gx, ldgx, workspace, b.slab);                                                  \
+                       m, gy, ldgy, gx, ldgx, workspace, b.slab, HeadBwdDesc{});                                   \
   } while (0)
   if (matches<NcfShape, true>(layers, nlayers, b.d)) CTR_LAUNCH_BWD(NcfShape, 14);
   else if (matches<NcfTowerShape, true>(layers, nlayers, b.d)) CTR_LAUNCH_BWD(NcfTowerShape, 12);
@@ -1102,4 +1199,51 @@ extern "C" int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp
     off += wn + layers[i].n;
   }
   return ctr_reduce_segments(workspace, (int)grid, b.slab, segs, st);
+}
+
+extern "C" int ctr_mlp_head_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
+                                const ctr_mlp_head_grad_t* hg, float* gx, int64_t ldgx, float* workspace,
+                                int64_t workspace_floats, void* stream) {
+  CTR_REQUIRE(m >= 0 && hg, CTR_EINVAL);
+  if (m == 0) return CTR_OK;
+  CTR_REQUIRE(x && workspace, CTR_EINVAL);
+  CTR_REQUIRE(ctr_aligned16(x) && ldx % 4 == 0, CTR_EALIGN);
+  CTR_REQUIRE(hg->prob && hg->gprob && hg->x && hg->w && hg->gx && hg->gw && hg->gc, CTR_EINVAL);
+  CTR_REQUIRE(hg->act >= CTR_ACT_NONE && hg->act <= CTR_ACT_SIGMOID && hg->ldprob >= 1 && hg->ldgprob >= 1, CTR_EINVAL);
+  Built b;
+  int rc = build(layers, nlayers, true, &b);
+  if (rc != CTR_OK) return rc;
+  CTR_REQUIRE(ldx >= b.d.l[0].k && (!gx || ldgx >= b.d.l[0].k), CTR_EINVAL);
+  // only the pinned NeuralCF tower with a 64-column extra operand has this path
+  if (!matches<NcfTowerShape, true>(layers, nlayers, b.d) || hg->p != kHeadBwdP) return CTR_ELIMIT;
+  CTR_REQUIRE(hg->ldx >= kHeadBwdP && hg->ldgx >= kHeadBwdP, CTR_EINVAL);
+  const ctr_mlp_layer_t& lastl = layers[nlayers - 1];
+  CTR_REQUIRE(ctr_aligned16(hg->x) && hg->ldx % 4 == 0 && ctr_aligned16(hg->gx) && hg->ldgx % 4 == 0 &&
+                  ctr_aligned16(lastl.y) && lastl.ldy % 4 == 0,
+              CTR_EALIGN);
+  const int64_t tiles = ctr_ceil_div(m, 32);
+  int64_t grid = ctr_ceil_div(tiles, kWaves);
+  if (grid > 256) grid = 256;
+  const int64_t slab = b.slab + kHeadBwdSums;
+  CTR_REQUIRE(workspace_floats >= grid * slab, CTR_ELIMIT);
+  hipStream_t st = (hipStream_t)stream;
+  rc = allow_lds(mlp_bwd_kernel<NcfTowerShape, 12, true>, b.lds_bytes);
+  if (rc != CTR_OK) return rc;
+  const HeadBwdDesc hb{hg->gprob, hg->ldgprob, hg->prob, hg->ldprob, hg->x, hg->ldx, hg->w, hg->gx, hg->ldgx, hg->act};
+  hipLaunchKernelGGL((mlp_bwd_kernel<NcfTowerShape, 12, true>), dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, st,
+                     b.d, x, ldx, m, nullptr, 0, gx, ldgx, workspace, slab, hb);
+  rc = ctr_launch_status();
+  if (rc != CTR_OK) return rc;
+  CtrSegments segs;
+  segs.n = 0;
+  int64_t off = 0;
+  for (int i = 0; i < nlayers; ++i) {
+    const int64_t wn = (int64_t)layers[i].n * layers[i].k;
+    segs.s[segs.n++] = CtrSegment{off, wn, layers[i].gw};
+    segs.s[segs.n++] = CtrSegment{off + wn, layers[i].n, layers[i].gb};
+    off += wn + layers[i].n;
+  }
+  segs.s[segs.n++] = CtrSegment{off, kHeadBwdP + kHeadBwdN, hg->gw};
+  segs.s[segs.n++] = CtrSegment{off + kHeadBwdP + kHeadBwdN, 1, hg->gc};
+  return ctr_reduce_segments(workspace, (int)grid, slab, segs, st);
 }

@@ -76,9 +76,15 @@ class _NeuralCFFunction(torch.autograd.Function):
         gwfold, gcfold = zeros[id(wfold)], list(zeros.values())[-1][:1]
         gbuf = torch.empty_like(buf)
         if n_hidden:
-            ops.linear_bwd(buf[:, l0:], wfold, prob, gprob.contiguous(), ACT_SIGMOID, gbuf[:, l0:], gwfold, gcfold)
             acts = [buf[:, :l0]] + mids + [buf[:, l0 + mf:]]
-            layer_grads, _ = ops.mlp_bwd(acts, hidden, gbuf[:, l0 + mf:], gbuf[:, :l0], zeros=zeros)
+            # head backward + tower backward in one launch where the library has it (the BASELINE tower) ...
+            head = ops.Head(buf[:, l0:l0 + mf], wfold, None, ACT_SIGMOID)
+            layer_grads = ops.mlp_head_bwd(acts, hidden, head, prob, gprob.contiguous(), gbuf[:, l0:l0 + mf], gwfold,
+                                           gcfold, gbuf[:, :l0], zeros)
+            if layer_grads is None:
+                # ... else the head as a single-unit layer on [gmf | h], then the tower
+                ops.linear_bwd(buf[:, l0:], wfold, prob, gprob.contiguous(), ACT_SIGMOID, gbuf[:, l0:], gwfold, gcfold)
+                layer_grads, _ = ops.mlp_bwd(acts, hidden, gbuf[:, l0 + mf:], gbuf[:, :l0], zeros=zeros)
         else:
             wf = torch.cat([wfold[:, mf:], wfold[:, :mf]], dim=1)
             gwf = torch.zeros_like(wf)

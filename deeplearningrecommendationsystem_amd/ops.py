@@ -432,6 +432,38 @@ def _head_unfused(head: Optional[Head], y_last: torch.Tensor) -> None:
     head.out = linear_fwd(operand, head.w, head.c, head.act)
 
 
+def mlp_head_bwd(acts: Sequence[torch.Tensor], layers: Sequence[Layer], head: Head, prob: torch.Tensor,
+                 gprob: torch.Tensor, g_extra: torch.Tensor, gw_head: torch.Tensor, gc_head: torch.Tensor,
+                 gx_first: torch.Tensor, zeros: dict):
+    """backward of ``mlp_fwd(..., head=head)`` in one launch (ctr_mlp_head_bwd): the head's gz, the stack's
+    backward, ``g_extra = gz * w[:p]`` and the head's weight / bias sums.  Returns the per-layer
+    ``[(gw, gb)]`` or None when the library has no fused path for this stack (nothing was enqueued)."""
+    if not _fusable(acts[0], layers) or head.x_extra is None:
+        return None
+    grads = [(zeros[id(layer.weight)], zeros[id(layer.bias)]) for layer in layers]
+    x0 = _mat(acts[0], "x")
+    m = x0.shape[0]
+    arr = _mlp_layer_array(layers, acts[1:], grads)
+    ws = _scratch(x0.device)
+    dims = [(layer.weight.shape[0], layer.weight.shape[1]) for layer in layers]
+    p = head.x_extra.shape[1]
+    prob, gprob = prob.reshape(-1), gprob.reshape(-1)
+    hg = _lib.MlpHeadGrad(prob.data_ptr(), prob.stride(0), gprob.data_ptr(), gprob.stride(0), head.x_extra.data_ptr(),
+                          _ld(head.x_extra), head.w.data_ptr(), g_extra.data_ptr(), _ld(g_extra), gw_head.data_ptr(),
+                          gc_head.data_ptr(), p, head.act)
+    rc = _timed("mlp_fused_bwd",
+                lambda: (4 * m * (2 * dims[0][1] + 2 * p + 2 + 2 * sum(n for n, _ in dims)),
+                         2 * m * (3 * sum(n * k for n, k in dims) - dims[0][0] * dims[0][1] + 2 * (p + dims[-1][0]))),
+                _lib.load().ctr_mlp_head_bwd, x0.data_ptr(), _ld(x0), m, arr, len(layers), C.byref(hg),
+                gx_first.data_ptr(), _ld(gx_first), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+    if rc in _REFUSED:
+        if _profiler is not None and _profiler.records and _profiler.records[-1][0] == "mlp_fused_bwd":
+            _profiler.records.pop()
+        return None
+    _lib.check(rc, "ctr_mlp_head_bwd")
+    return grads
+
+
 def mlp_bwd(acts: Sequence[torch.Tensor], layers: Sequence[Layer], gy: torch.Tensor,
             gx_first: Optional[torch.Tensor], want_gx_first: bool = True, zeros: Optional[dict] = None):
     """backward through ``mlp_fwd``; returns ([(gw, gb) per layer], gx of the

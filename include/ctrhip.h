@@ -315,6 +315,25 @@ typedef struct ctr_mlp_head {
 } ctr_mlp_head_t;
 int ctr_mlp_head_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
                      const ctr_mlp_head_t* head, void* stream);
+/* Backward of ctr_mlp_head_fwd in ONE launch with the stack's backward: per row gz = gprob * act'(prob);
+ * the stack's gY is gz * w[p:] (never stored), gx_extra[row, 0:p] = gz * w[0:p] is written, and
+ * gw[0:p+n_last] += sum_rows gz * [x_extra | y_last],  gc[0] += sum_rows gz.  Layers' gw / gb and gx as in
+ * ctr_mlp_bwd.  Available for the pinned NeuralCF tower (128-64-32-16-8, relu) with p == 64 only; any other
+ * stack returns CTR_ELIMIT without enqueueing (then: ctr_linear_bwd on the head + ctr_mlp_bwd).
+ * workspace: (workgroups <= 256) * (sum_i (n_i*k_i + n_i) + p + n_last + 1) floats. */
+typedef struct ctr_mlp_head_grad {
+  const float* prob;  int64_t ldprob;   /* head output (m), as written by ctr_mlp_head_fwd */
+  const float* gprob; int64_t ldgprob;  /* its gradient (m) */
+  const float* x;     int64_t ldx;      /* the p extra input columns */
+  const float* w;                       /* p + n_last head weights */
+  float* gx;          int64_t ldgx;     /* gradient of the extra columns, written (=) */
+  float* gw;                            /* p + n_last, accumulated */
+  float* gc;                            /* 1, accumulated */
+  int32_t p, act;
+} ctr_mlp_head_grad_t;
+int ctr_mlp_head_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
+                     const ctr_mlp_head_grad_t* head, float* gx, int64_t ldgx, float* workspace,
+                     int64_t workspace_floats, void* stream);
 /* gy: gradient of the LAST layer's output; gx (nullable): gradient of x.  workspace is
  * required: (number of workgroups <= 256) * sum_i (n_i*k_i + n_i) floats. */
 int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,

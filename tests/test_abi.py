@@ -51,6 +51,8 @@ def test_field_struct_matches_header_size(lib):
     assert ctypes.sizeof(lib.MlpLayer) == 64
     # pointer + int64 + 3 pointers + int64 + 2 int32 = 56 bytes, as ctr_mlp_head_t
     assert ctypes.sizeof(lib.MlpHead) == 56
+    # 11 pointers / int64 + 2 int32 = 96 bytes, as ctr_mlp_head_grad_t
+    assert ctypes.sizeof(lib.MlpHeadGrad) == 96
 
 
 def test_strerror(lib):
@@ -102,6 +104,8 @@ def _parse_header_prototypes():
                     kinds.append("field*")
                 elif "ctr_mlp_layer_t" in a:
                     kinds.append("mlp*")
+                elif "ctr_mlp_head_grad_t" in a:
+                    kinds.append("headgrad*")
                 elif "ctr_mlp_head_t" in a:
                     kinds.append("head*")
                 elif "ctr_adam_tensor_t" in a:
@@ -141,6 +145,8 @@ def test_ctypes_signatures_match_header_prototypes(lib):
                 got.append("mlp*")
             elif a is ctypes.POINTER(lib.MlpHead):
                 got.append("head*")
+            elif a is ctypes.POINTER(lib.MlpHeadGrad):
+                got.append("headgrad*")
             elif a is ctypes.POINTER(lib.AdamTensor):
                 got.append("adam*")
             elif a is ctypes.c_float:

@@ -290,6 +290,56 @@ def test_mlp_forward_with_fused_head(ops, dims, p):
     torch.testing.assert_close(head.out.cpu(), ref.float(), rtol=1e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("m", [4096, 1000, 37])
+def test_mlp_backward_with_fused_head_matches_autograd(ops, m):
+    """ctr_mlp_head_bwd (pinned NeuralCF tower, 64 extra columns): gradients of every layer, of the stack
+    input, of the extra columns and of the head's weights / bias against fp64 autograd"""
+    dims, p = [128, 64, 32, 16, 8], 64
+    g = torch.Generator().manual_seed(m)
+    x0 = torch.randn(m, dims[0], generator=g)
+    xe = torch.randn(m, p, generator=g)
+    ws = [torch.randn(n, k, generator=g) / k ** 0.5 for k, n in zip(dims[:-1], dims[1:])]
+    bs = [torch.randn(n, generator=g) * 0.1 for n in dims[1:]]
+    wh, ch = torch.randn(1, p + dims[-1], generator=g) * 0.3, torch.randn(1, generator=g)
+    gprob = torch.randn(m, 1, generator=g)
+    # fp64 reference
+    leaves = [t.double().requires_grad_(True) for t in [x0, xe, wh, ch] + ws + bs]
+    rx0, rxe, rwh, rch = leaves[:4]
+    rws, rbs = leaves[4:4 + len(ws)], leaves[4 + len(ws):]
+    hcur = rx0
+    for w_, b_ in zip(rws, rbs):
+        hcur = torch.relu(hcur @ w_.T + b_)
+    prob_ref = torch.sigmoid(torch.cat([rxe, hcur], dim=1) @ rwh.T + rch)
+    prob_ref.backward(gprob.double())
+    # device: forward with the fused head, then the fused backward
+    buf = torch.zeros(m, dims[0] + p + dims[-1], device=DEV)
+    buf[:, :dims[0]] = x0.to(DEV)
+    buf[:, dims[0]:dims[0] + p] = xe.to(DEV)
+    layers = [ops.Layer(w_.to(DEV), b_.to(DEV), 1) for w_, b_ in zip(ws, bs)]
+    dwh, dch = wh.to(DEV), ch.to(DEV)
+    head = ops.Head(buf[:, dims[0]:dims[0] + p], dwh, dch, 2)
+    acts = ops.mlp_fwd(buf[:, :dims[0]], layers, last_out=buf[:, dims[0] + p:], head=head)
+    torch.testing.assert_close(head.out.cpu(), prob_ref.detach().float(), rtol=1e-5, atol=2e-6)
+    params = [l.weight for l in layers] + [l.bias for l in layers]
+    zeros = ops.zero_grads(params + [dwh, dch.new_empty(4)])
+    gwh, gch = zeros[id(dwh)], list(zeros.values())[-1][:1]
+    gbuf = torch.full_like(buf, float("nan"))
+    grads = ops.mlp_head_bwd(acts, layers, head, head.out, gprob.to(DEV), gbuf[:, dims[0]:dims[0] + p], gwh, gch,
+                             gbuf[:, :dims[0]], zeros)
+    if m < 1024:  # ops fuses stacks from 1024 rows up: below that the caller runs the head and the stack separately
+        assert grads is None
+        return
+    assert grads is not None, "the pinned tower must take the fused path"
+    scale = max(1.0, m ** 0.5)
+    torch.testing.assert_close(gbuf[:, :dims[0]].cpu(), rx0.grad.float(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gbuf[:, dims[0]:dims[0] + p].cpu(), rxe.grad.float(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gwh.cpu(), rwh.grad.float(), rtol=1e-5, atol=2e-6 * scale)
+    torch.testing.assert_close(gch.cpu(), rch.grad.float(), rtol=1e-5, atol=2e-6 * scale)
+    for (gw, gb), rw, rb in zip(grads, rws, rbs):
+        torch.testing.assert_close(gw.cpu(), rw.grad.float(), rtol=1e-5, atol=2e-6 * scale)
+        torch.testing.assert_close(gb.cpu(), rb.grad.float(), rtol=1e-5, atol=2e-6 * scale)
+
+
 def test_fold_head_matches_the_unfolded_pair(ops):
     """(h W^T + b).u + b2 == h.v + c and its chain rule (ctr_fold_head_fwd/bwd) against autograd on the
     unfolded expression"""
