@@ -452,8 +452,10 @@ def mlp_head_bwd(acts: Sequence[torch.Tensor], layers: Sequence[Layer], head: He
                           _ld(head.x_extra), head.w.data_ptr(), g_extra.data_ptr(), _ld(g_extra), gw_head.data_ptr(),
                           gc_head.data_ptr(), p, head.act)
     rc = _timed("mlp_fused_bwd",
-                lambda: (4 * m * (2 * dims[0][1] + 2 * p + 2 + 2 * sum(n for n, _ in dims)),
-                         2 * m * (3 * sum(n * k for n, k in dims) - dims[0][0] * dims[0][1] + 2 * (p + dims[-1][0]))),
+                # read: stack input, every saved activation, the extra columns, prob, gprob; written: gX, g_extra.
+                # flops: dW + dX of every layer, the head's products and sums
+                lambda: (4 * m * (2 * dims[0][1] + sum(n for n, _ in dims) + 2 * p + 2),
+                         4 * m * (sum(n * k for n, k in dims) + p + dims[-1][0])),
                 _lib.load().ctr_mlp_head_bwd, x0.data_ptr(), _ld(x0), m, arr, len(layers), C.byref(hg),
                 gx_first.data_ptr(), _ld(gx_first), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
     if rc in _REFUSED:
