@@ -120,6 +120,9 @@ int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x,
 int ctr_embed_bwd_bags(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch,
                        const float* gout, int64_t ldo, float* workspace, int64_t workspace_floats,
                        int64_t* used_floats, unsigned char* handled, hipStream_t st);
+// embed_bag.hip: forward of the wide bag fields in a kernel of their own (see there)
+int ctr_embed_fwd_bags(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch, float* out,
+                       int64_t ldo, unsigned char* handled, hipStream_t st);
 // linear_skinny.hip: weight gradient of a layer with few units on both sides over a very long batch
 bool ctr_skinny_dw_ok(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
                       const float* gw, int64_t ldgw, int64_t m, int n, int k, int act);

@@ -405,6 +405,21 @@ extern "C" int ctr_embed_fwd(const ctr_field_t* fields, int nfields, const float
   if (rc != CTR_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (try_fast_ids(fields, nfields, batch, out, ldo, err_flag, st, &rc)) return rc;
+  // wide bag fields run in a kernel of their own (embed_bag.hip); the gather kernel takes the rest
+  unsigned char handled[CTR_MAX_FIELDS];
+  rc = ctr_embed_fwd_bags(fields, nfields, x, ldx, batch, out, ldo, handled, st);
+  if (rc != CTR_OK) return rc;
+  ctr_field_t rest[CTR_MAX_FIELDS];
+  int nrest = 0;
+  for (int i = 0; i < nfields; ++i)
+    if (!handled[i]) rest[nrest++] = fields[i];
+  if (nrest == 0) return CTR_OK;
+  if (nrest < nfields) {
+    fields = rest;
+    nfields = nrest;
+    rc = make_plan(fields, nfields, x, ldx, out, ldo, false, &plan);
+    if (rc != CTR_OK) return rc;
+  }
   CTR_REQUIRE(batch * plan.units < (1ll << 32), CTR_ELIMIT);
   const CtrFastDiv div = ctr_fastdiv((uint32_t)plan.units);
   const int grid = ctr_stream_grid(batch * plan.units, kBlock);
