@@ -1,4 +1,5 @@
-for w in neuralcf deepfm pnn deepcrossing widedeep nfm afm; do
+# dev tool: one bench line per workload (no CPU baseline), summary table at the end
+for w in neuralcf mf deepfm pnn ffm deepcrossing widedeep nfm afm lr gather26; do
   python bench.py --workload $w --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/bench_$w.json 2>gpurun_out/bench_$w.err || { echo FAIL $w; tail -5 gpurun_out/bench_$w.err; }
 done
 for w in din dien deepcross; do
