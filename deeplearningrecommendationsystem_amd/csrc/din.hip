@@ -131,7 +131,43 @@ pool_fwd_kernel(const SeqGeom g, const float* __restrict__ score, const float* _
     for (int q = 0; q < 8; ++q)
 #pragma unroll
       for (int v = 0; v < VEC; ++v) acc[q][v] = 0.0f;
-    for (int l0 = 0; l0 < g.len; l0 += rows_per_iter) {
+    int l0 = 0;
+    if (chunks == 1) {
+      // a row fits one chunk per lane (E <= lpr * VEC, the BASELINE shapes): four row groups in flight --
+      // one group at a time is a load-use loop that leaves the kernel latency-bound; same FMA order
+      const int e = sub * VEC;
+      const bool live = e < g.dim;
+      for (; l0 + 3 * rows_per_iter < g.len; l0 += 4 * rows_per_iter) {
+        Pack<VEC> h4[4];
+        float al4[4];
+        bool ok4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int l = l0 + u * rows_per_iter + rsub;
+          ok4[u] = live && l < g.len;
+          const int lc = l < g.len ? l : g.len - 1;
+          al4[u] = expf(s[lc] - mx) / den;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) h4[u].v[v] = 0.0f;
+          if (ok4[u]) h4[u].load(hsrc + (b * g.len + l) * ldh + e);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (!ok4[u]) continue;
+          if (summed) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[0][v] = fmaf(al4[u], h4[u].v[v], acc[0][v]);
+          } else {
+            const int l = l0 + u * rows_per_iter + rsub;
+            Pack<VEC> o;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o.v[v] = h4[u].v[v] * al4[u];
+            o.store(out + (b * g.len + l) * ldo + e);
+          }
+        }
+      }
+    }
+    for (; l0 < g.len; l0 += rows_per_iter) {
       const int l = l0 + rsub;
       if (l < g.len) {
         const float al = expf(s[l] - mx) / den;
@@ -195,7 +231,41 @@ pool_bwd_kernel(const SeqGeom g, const float* __restrict__ attn, const float* __
     float dotsum = 0.0f;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
-      for (int l0 = 0; l0 < g.len; l0 += rows_per_iter) {
+      int l0 = 0;
+      if (g.dim <= g.lpr * VEC) {
+        // single chunk per lane: four row groups in flight (see pool_fwd_kernel); per row the same dot product
+        // and the same order of the dotsum / gscore updates
+        const int e = sub * VEC;
+        const bool live = e < g.dim;
+        for (; l0 + 3 * rows_per_iter < g.len; l0 += 4 * rows_per_iter) {
+          float ga4[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int l = l0 + u * rows_per_iter + rsub;
+            ga4[u] = 0.0f;
+            if (live && l < g.len) {
+              Pack<VEC> h, q;
+              h.load(hsrc + (b * g.len + l) * ldh + e);
+              q.load((summed ? gout + b * ldgo : gout + (b * g.len + l) * ldgo) + e);
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) ga4[u] = fmaf(q.v[v], h.v[v], ga4[u]);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int l = l0 + u * rows_per_iter + rsub;
+            float ga = ga4[u];
+            for (int o = g.lpr >> 1; o > 0; o >>= 1) ga += __shfl_xor(ga, o, 64);
+            if (l < g.len && sub == 0) {
+              if (pass == 0)
+                dotsum = fmaf(ab[l], ga, dotsum);
+              else
+                gs[l] = ab[l] * (ga - dotsum);
+            }
+          }
+        }
+      }
+      for (; l0 < g.len; l0 += rows_per_iter) {
         const int l = l0 + rsub;
         float ga = 0.0f;
         if (l < g.len) {
