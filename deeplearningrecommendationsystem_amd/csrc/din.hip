@@ -238,11 +238,12 @@ pool_bwd_kernel(const SeqGeom g, const float* __restrict__ attn, const float* __
         const int e = sub * VEC;
         const bool live = e < g.dim;
         for (; l0 + 3 * rows_per_iter < g.len; l0 += 4 * rows_per_iter) {
-          float ga4[4];
+          float ga4[4], ab4[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int l = l0 + u * rows_per_iter + rsub;
             ga4[u] = 0.0f;
+            ab4[u] = ab[l < g.len ? l : g.len - 1];  // requested with the rows, not after the reduction
             if (live && l < g.len) {
               Pack<VEC> h, q;
               h.load(hsrc + (b * g.len + l) * ldh + e);
@@ -258,9 +259,9 @@ pool_bwd_kernel(const SeqGeom g, const float* __restrict__ attn, const float* __
             for (int o = g.lpr >> 1; o > 0; o >>= 1) ga += __shfl_xor(ga, o, 64);
             if (l < g.len && sub == 0) {
               if (pass == 0)
-                dotsum = fmaf(ab[l], ga, dotsum);
+                dotsum = fmaf(ab4[u], ga, dotsum);
               else
-                gs[l] = ab[l] * (ga - dotsum);
+                gs[l] = ab4[u] * (ga - dotsum);
             }
           }
         }
