@@ -22,11 +22,53 @@ struct N1Args {
   int64_t m; int k; int act; int lpr;
 };
 
-template <int VEC>
+// U > 1: the row fits a single chunk per lane (k <= lpr * VEC) and U rows are in flight per lane group --
+// one row at a time is a load-use loop that leaves the kernel latency-bound on long batches.
+template <int VEC, int U>
 __global__ void __launch_bounds__(kBlock) n1_fwd_kernel(const N1Args a) {
   const int sub = threadIdx.x % a.lpr;
   const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / a.lpr;
   const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / a.lpr;
+  if constexpr (U > 1) {
+    const int c = sub * VEC;
+    const bool live = c < a.k;
+    float wv[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) wv[v] = live ? a.w[c + v] : 0.0f;
+    const float bias = a.bias ? a.bias[0] : 0.0f;
+    for (int64_t r0 = gid; r0 < a.m; r0 += groups * U) {
+      float xv[U][VEC];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t r = r0 + u * groups;
+        const int64_t rc = r < a.m ? r : a.m - 1;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) xv[u][v] = 0.0f;
+        if (live) {
+          if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(a.x + rc * a.ldx + c);
+            xv[u][0] = t.x; xv[u][1] = t.y; xv[u][2] = t.z; xv[u][VEC - 1] = t.w;
+          } else {
+            xv[u][0] = a.x[rc * a.ldx + c];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t r = r0 + u * groups;
+        float acc = 0.0f;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc = fmaf(xv[u][v], wv[v], acc);
+        for (int o = a.lpr >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (sub == 0 && r < a.m) {
+          float z = acc + bias;
+          if (a.res) z += a.res[r * a.ldr];
+          a.y[r * a.ldy] = ctr_act(z, a.act);
+        }
+      }
+    }
+    return;
+  }
   for (int64_t r = gid; r < a.m; r += groups) {
     const float* xr = a.x + r * a.ldx;
     float acc = 0.0f;
@@ -221,11 +263,13 @@ int ctr_n1_fwd(const float* x, int64_t ldx, const float* w, const float* bias, c
   int lpr = pow2_ceil(units);
   if (lpr > 64) lpr = 64;
   N1Args a{x, ldx, w, bias, res, ldr, y, ldy, m, k, act, lpr};
-  const int grid = ctr_stream_grid(m * lpr, kBlock);
-  if (vec)
-    hipLaunchKernelGGL(n1_fwd_kernel<4>, dim3(grid), dim3(kBlock), 0, st, a);
-  else
-    hipLaunchKernelGGL(n1_fwd_kernel<1>, dim3(grid), dim3(kBlock), 0, st, a);
+  // one chunk per lane and a long batch: four rows in flight per lane group
+  const bool single = (vec ? 4 : 1) * lpr >= k && m >= 262144;
+  const int grid = ctr_stream_grid(single ? ctr_ceil_div(m * lpr, 4) : m * lpr, kBlock);
+  if (vec && single) hipLaunchKernelGGL((n1_fwd_kernel<4, 4>), dim3(grid), dim3(kBlock), 0, st, a);
+  else if (vec) hipLaunchKernelGGL((n1_fwd_kernel<4, 1>), dim3(grid), dim3(kBlock), 0, st, a);
+  else if (single) hipLaunchKernelGGL((n1_fwd_kernel<1, 4>), dim3(grid), dim3(kBlock), 0, st, a);
+  else hipLaunchKernelGGL((n1_fwd_kernel<1, 1>), dim3(grid), dim3(kBlock), 0, st, a);
   return ctr_launch_status();
 }
 
