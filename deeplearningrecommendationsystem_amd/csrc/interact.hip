@@ -786,26 +786,45 @@ pairprod_fwd_kernel(const float* __restrict__ emb, int64_t lde, int64_t batch, i
   }
 }
 
-template <int NV>
+template <int NV, int VEC>
 __global__ void __launch_bounds__(kBiBlock)
 pairprod_bwd_kernel(const float* __restrict__ emb, int64_t lde, int64_t batch, int nvec, int dim,
                     const float* __restrict__ gp, int64_t ldgp, const float* __restrict__ attn,
                     const float* __restrict__ gpool, int64_t ldgo, float* __restrict__ gemb, int64_t ldg,
                     int accumulate) {
+  // VEC = 4: a thread owns 4 consecutive elements (16-byte loads / stores; dim % 4 == 0, aligned rows)
   const int np = nvec * (nvec - 1) / 2;
-  const int64_t total = batch * dim;
+  const int dv = dim / VEC;
+  const int64_t total = batch * dv;
   const bool pooled = attn && gpool;
   for (int64_t g = (int64_t)blockIdx.x * kBiBlock + threadIdx.x; g < total; g += (int64_t)gridDim.x * kBiBlock) {
-    const int64_t b = g / dim;
-    const int e = (int)(g - b * dim);
+    const int64_t b = g / dv;
+    const int e = (int)(g - b * dv) * VEC;
     const float* v = emb + b * lde + e;
     const float* q = gp + b * np * ldgp + e;
-    const float go = pooled ? gpool[b * ldgo + e] : 0.0f;
-    float vv[NV], acc[NV];
+    float go[VEC], vv[NV][VEC], acc[NV][VEC];
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) go[u] = 0.0f;
+    if (pooled) {
+      if (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(gpool + b * ldgo + e);
+        go[0] = t.x; go[1] = t.y; go[2] = t.z; go[VEC - 1] = t.w;
+      } else {
+        go[0] = gpool[b * ldgo + e];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      vv[i] = i < nvec ? v[(int64_t)i * dim] : 0.0f;
-      acc[i] = 0.0f;
+#pragma unroll
+      for (int u = 0; u < VEC; ++u) vv[i][u] = acc[i][u] = 0.0f;
+      if (i < nvec) {
+        if (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(v + (int64_t)i * dim);
+          vv[i][0] = t.x; vv[i][1] = t.y; vv[i][2] = t.z; vv[i][VEC - 1] = t.w;
+        } else {
+          vv[i][0] = v[(int64_t)i * dim];
+        }
+      }
     }
     int p = 0;
 #pragma unroll
@@ -813,16 +832,38 @@ pairprod_bwd_kernel(const float* __restrict__ emb, int64_t lde, int64_t batch, i
 #pragma unroll
       for (int j = i + 1; j < NV; ++j)
         if (j < nvec) {
-          float gpair = q[(int64_t)p * ldgp];
-          if (pooled) gpair = fmaf(attn[b * np + p], go, gpair);
-          acc[i] = fmaf(gpair, vv[j], acc[i]);
-          acc[j] = fmaf(gpair, vv[i], acc[j]);
+          float gpair[VEC];
+          if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(q + (int64_t)p * ldgp);
+            gpair[0] = t.x; gpair[1] = t.y; gpair[2] = t.z; gpair[VEC - 1] = t.w;
+          } else {
+            gpair[0] = q[(int64_t)p * ldgp];
+          }
+          const float at = pooled ? attn[b * np + p] : 0.0f;
+#pragma unroll
+          for (int u = 0; u < VEC; ++u) {
+            if (pooled) gpair[u] = fmaf(at, go[u], gpair[u]);
+            acc[i][u] = fmaf(gpair[u], vv[j][u], acc[i][u]);
+            acc[j][u] = fmaf(gpair[u], vv[i][u], acc[j][u]);
+          }
           ++p;
         }
     float* o = gemb + b * ldg + e;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-      if (i < nvec) o[(int64_t)i * dim] = accumulate ? o[(int64_t)i * dim] + acc[i] : acc[i];
+      if (i < nvec) {
+        float* oi = o + (int64_t)i * dim;
+        if (VEC == 4) {
+          float4 t = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][VEC - 1]);
+          if (accumulate) {
+            const float4 old = *reinterpret_cast<const float4*>(oi);
+            t = make_float4(old.x + t.x, old.y + t.y, old.z + t.z, old.w + t.w);
+          }
+          *reinterpret_cast<float4*>(oi) = t;
+        } else {
+          oi[0] = accumulate ? oi[0] + acc[i][0] : acc[i][0];
+        }
+      }
   }
 }
 
@@ -858,11 +899,19 @@ extern "C" int ctr_pairprod_bwd(const float* emb, int64_t lde, int64_t batch, in
   CTR_REQUIRE(emb && gp && gemb && nvec >= 2 && nvec <= 16 && dim > 0, CTR_EINVAL);
   CTR_REQUIRE(lde >= (int64_t)nvec * dim && ldg >= (int64_t)nvec * dim && ldgp >= dim, CTR_EINVAL);
   CTR_REQUIRE((attn == nullptr) == (gpool == nullptr) && (!gpool || ldgo >= dim), CTR_EINVAL);
-  const dim3 grid(ctr_stream_grid(batch * dim, kBiBlock));
+  const bool vec4 = dim % 4 == 0 && lde % 4 == 0 && ldgp % 4 == 0 && ldg % 4 == 0 && ctr_aligned16(emb) &&
+                    ctr_aligned16(gp) && ctr_aligned16(gemb) && (!gpool || (ldgo % 4 == 0 && ctr_aligned16(gpool)));
+  const dim3 grid(ctr_stream_grid(batch * (dim / (vec4 ? 4 : 1)), kBiBlock));
   hipStream_t st = (hipStream_t)stream;
-#define CTR_PP(NV_)                                                                                                 \
-  hipLaunchKernelGGL(pairprod_bwd_kernel<NV_>, grid, dim3(kBiBlock), 0, st, emb, lde, batch, nvec, dim, gp, ldgp, attn, \
-                     gpool, ldgo, gemb, ldg, accumulate)
+#define CTR_PP(NV_)                                                                                                    \
+  do {                                                                                                                 \
+    if (vec4)                                                                                                          \
+      hipLaunchKernelGGL((pairprod_bwd_kernel<NV_, 4>), grid, dim3(kBiBlock), 0, st, emb, lde, batch, nvec, dim, gp, ldgp, \
+                         attn, gpool, ldgo, gemb, ldg, accumulate);                                                    \
+    else                                                                                                               \
+      hipLaunchKernelGGL((pairprod_bwd_kernel<NV_, 1>), grid, dim3(kBiBlock), 0, st, emb, lde, batch, nvec, dim, gp, ldgp, \
+                         attn, gpool, ldgo, gemb, ldg, accumulate);                                                    \
+  } while (0)
   switch (nvec) {
     case 2: CTR_PP(2); break;
     case 3: CTR_PP(3); break;
