@@ -687,39 +687,86 @@ namespace {
 
 constexpr int kBiBlock = 256;
 
+// VEC = 4: a thread owns 4 consecutive elements of a sample (16-byte loads / stores) when dim % 4 == 0 and every
+// row is 16-byte aligned; the per-element arithmetic and its order are the same as with VEC = 1.
+template <int VEC>
+struct BiVec {
+  float v[VEC];
+  __device__ __forceinline__ void load(const float* p) {
+    if (VEC == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(p);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[VEC - 1] = t.w;
+    } else {
+      v[0] = *p;
+    }
+  }
+  __device__ __forceinline__ void store(float* p) const {
+    if (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[VEC - 1]);
+    else *p = v[0];
+  }
+};
+
+template <int VEC>
 __global__ void __launch_bounds__(kBiBlock)
 biinteract_fwd_kernel(const float* __restrict__ emb, int64_t lde, int64_t batch, int nvec, int dim,
                       float* __restrict__ out, int64_t ldo) {
-  const int64_t total = batch * dim;
+  const int dv = dim / VEC;
+  const int64_t total = batch * dv;
   for (int64_t g = (int64_t)blockIdx.x * kBiBlock + threadIdx.x; g < total; g += (int64_t)gridDim.x * kBiBlock) {
-    const int64_t b = g / dim;
-    const int e = (int)(g - b * dim);
+    const int64_t b = g / dv;
+    const int e = (int)(g - b * dv) * VEC;
     const float* v = emb + b * lde + e;
-    float acc = 0.0f;
+    BiVec<VEC> acc;
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) acc.v[u] = 0.0f;
     for (int i = 0; i < nvec; ++i) {
-      const float vi = v[(int64_t)i * dim];
-      for (int j = i + 1; j < nvec; ++j) acc += vi * v[(int64_t)j * dim];
+      BiVec<VEC> vi;
+      vi.load(v + (int64_t)i * dim);
+      for (int j = i + 1; j < nvec; ++j) {
+        BiVec<VEC> vj;
+        vj.load(v + (int64_t)j * dim);
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) acc.v[u] += vi.v[u] * vj.v[u];
+      }
     }
-    out[b * ldo + e] = acc;
+    acc.store(out + b * ldo + e);
   }
 }
 
+template <int VEC>
 __global__ void __launch_bounds__(kBiBlock)
 biinteract_bwd_kernel(const float* __restrict__ emb, int64_t lde, int64_t batch, int nvec, int dim,
                       const float* __restrict__ gout, int64_t ldgo, float* __restrict__ gemb, int64_t ldg,
                       int accumulate) {
-  const int64_t total = batch * dim;
+  const int dv = dim / VEC;
+  const int64_t total = batch * dv;
   for (int64_t g = (int64_t)blockIdx.x * kBiBlock + threadIdx.x; g < total; g += (int64_t)gridDim.x * kBiBlock) {
-    const int64_t b = g / dim;
-    const int e = (int)(g - b * dim);
+    const int64_t b = g / dv;
+    const int e = (int)(g - b * dv) * VEC;
     const float* v = emb + b * lde + e;
-    float sum = 0.0f;
-    for (int i = 0; i < nvec; ++i) sum += v[(int64_t)i * dim];
-    const float go = gout[b * ldgo + e];
+    BiVec<VEC> sum, go;
+#pragma unroll
+    for (int u = 0; u < VEC; ++u) sum.v[u] = 0.0f;
+    for (int i = 0; i < nvec; ++i) {
+      BiVec<VEC> vi;
+      vi.load(v + (int64_t)i * dim);
+#pragma unroll
+      for (int u = 0; u < VEC; ++u) sum.v[u] += vi.v[u];
+    }
+    go.load(gout + b * ldgo + e);
     float* o = gemb + b * ldg + e;
     for (int i = 0; i < nvec; ++i) {
-      const float val = go * (sum - v[(int64_t)i * dim]);
-      o[(int64_t)i * dim] = accumulate ? o[(int64_t)i * dim] + val : val;
+      BiVec<VEC> vi, val;
+      vi.load(v + (int64_t)i * dim);
+#pragma unroll
+      for (int u = 0; u < VEC; ++u) val.v[u] = go.v[u] * (sum.v[u] - vi.v[u]);
+      if (accumulate) {
+        BiVec<VEC> old;
+        old.load(o + (int64_t)i * dim);
+#pragma unroll
+        for (int u = 0; u < VEC; ++u) val.v[u] = old.v[u] + val.v[u];
+      }
+      val.store(o + (int64_t)i * dim);
     }
   }
 }
@@ -731,8 +778,12 @@ extern "C" int ctr_biinteract_fwd(const float* emb, int64_t lde, int64_t batch, 
   CTR_REQUIRE(batch >= 0, CTR_EINVAL);
   if (batch == 0) return CTR_OK;
   CTR_REQUIRE(emb && out && nvec >= 1 && nvec <= 64 && dim > 0 && lde >= (int64_t)nvec * dim && ldo >= dim, CTR_EINVAL);
-  hipLaunchKernelGGL(biinteract_fwd_kernel, dim3(ctr_stream_grid(batch * dim, kBiBlock)), dim3(kBiBlock), 0,
-                     (hipStream_t)stream, emb, lde, batch, nvec, dim, out, ldo);
+  if (dim % 4 == 0 && lde % 4 == 0 && ldo % 4 == 0 && ctr_aligned16(emb) && ctr_aligned16(out))
+    hipLaunchKernelGGL(biinteract_fwd_kernel<4>, dim3(ctr_stream_grid(batch * (dim / 4), kBiBlock)), dim3(kBiBlock), 0,
+                       (hipStream_t)stream, emb, lde, batch, nvec, dim, out, ldo);
+  else
+    hipLaunchKernelGGL(biinteract_fwd_kernel<1>, dim3(ctr_stream_grid(batch * dim, kBiBlock)), dim3(kBiBlock), 0,
+                       (hipStream_t)stream, emb, lde, batch, nvec, dim, out, ldo);
   return ctr_launch_status();
 }
 
@@ -742,8 +793,13 @@ extern "C" int ctr_biinteract_bwd(const float* emb, int64_t lde, int64_t batch, 
   if (batch == 0) return CTR_OK;
   CTR_REQUIRE(emb && gout && gemb && nvec >= 1 && nvec <= 64 && dim > 0, CTR_EINVAL);
   CTR_REQUIRE(lde >= (int64_t)nvec * dim && ldg >= (int64_t)nvec * dim && ldgo >= dim, CTR_EINVAL);
-  hipLaunchKernelGGL(biinteract_bwd_kernel, dim3(ctr_stream_grid(batch * dim, kBiBlock)), dim3(kBiBlock), 0,
-                     (hipStream_t)stream, emb, lde, batch, nvec, dim, gout, ldgo, gemb, ldg, accumulate);
+  if (dim % 4 == 0 && lde % 4 == 0 && ldgo % 4 == 0 && ldg % 4 == 0 && ctr_aligned16(emb) && ctr_aligned16(gout) &&
+      ctr_aligned16(gemb))
+    hipLaunchKernelGGL(biinteract_bwd_kernel<4>, dim3(ctr_stream_grid(batch * (dim / 4), kBiBlock)), dim3(kBiBlock), 0,
+                       (hipStream_t)stream, emb, lde, batch, nvec, dim, gout, ldgo, gemb, ldg, accumulate);
+  else
+    hipLaunchKernelGGL(biinteract_bwd_kernel<1>, dim3(ctr_stream_grid(batch * dim, kBiBlock)), dim3(kBiBlock), 0,
+                       (hipStream_t)stream, emb, lde, batch, nvec, dim, gout, ldgo, gemb, ldg, accumulate);
   return ctr_launch_status();
 }
 
