@@ -137,7 +137,7 @@ pool_fwd_kernel(const SeqGeom g, const float* __restrict__ score, const float* _
       // one group at a time is a load-use loop that leaves the kernel latency-bound; same FMA order
       const int e = sub * VEC;
       const bool live = e < g.dim;
-      for (; l0 + 3 * rows_per_iter < g.len; l0 += 4 * rows_per_iter) {
+      for (; l0 < g.len; l0 += 4 * rows_per_iter) {  // every group guarded: the tail runs here too
         Pack<VEC> h4[4];
         float al4[4];
         bool ok4[4];
@@ -237,7 +237,7 @@ pool_bwd_kernel(const SeqGeom g, const float* __restrict__ attn, const float* __
         // and the same order of the dotsum / gscore updates
         const int e = sub * VEC;
         const bool live = e < g.dim;
-        for (; l0 + 3 * rows_per_iter < g.len; l0 += 4 * rows_per_iter) {
+        for (; l0 < g.len; l0 += 4 * rows_per_iter) {  // every group guarded: the tail runs here too
           float ga4[4], ab4[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
