@@ -14,7 +14,8 @@
  *    elements (ld*); indices are int64 as `nn.Embedding` takes them;
  *  - `stream` is a hipStream_t; every call only enqueues work on it, never
  *    allocates, never synchronises, keeps no state between calls and is
- *    re-entrant per stream;
+ *    re-entrant per stream (one caller-owned exception: the ticket word of
+ *    ctr_bce_fwd, zero before and after every call);
  *  - return value: 0 = enqueued, <0 = CTR_E* (nothing enqueued).  Never
  *    throws, never exits.  ctr_strerror() names a code;
  *  - out-of-range indices never fault: the row is treated as row 0 and, when
