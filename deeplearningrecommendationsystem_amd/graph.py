@@ -35,11 +35,14 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         model.zero_grad(set_to_none=True)
+        # the root gradient of loss.backward() is a constant 1: made once here instead of by a fill
+        # kernel inside every replay
+        self._one = torch.ones((), dtype=torch.float32, device=target.device)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.prob = model(*self.inputs)
             self.loss = loss_fn(self.prob, self.target)
-            self.loss.backward()
+            self.loss.backward(self._one)
 
     def _eager(self):
         self.model.zero_grad(set_to_none=True)
