@@ -16,7 +16,8 @@ constexpr int kBlock = 256;
 // launches before -- memset, partials, reduction -- at ~4.5 us each on a 220 us step.)
 __global__ void __launch_bounds__(kBlock)
 bce_fwd_kernel(const float* __restrict__ p, int64_t ldp, const float* __restrict__ y, int64_t ldy, int64_t n,
-               float inv_n, float* __restrict__ partial, unsigned int* __restrict__ ticket, float* __restrict__ loss) {
+               float inv_n, float* __restrict__ partial, unsigned int* __restrict__ ticket, float* __restrict__ loss,
+               float* __restrict__ gp1 /* nullable: d loss / d p for an upstream gradient of exactly 1 */) {
   __shared__ float s_red[kBlock / 64];
   __shared__ bool s_last;
   float acc = 0.0f;
@@ -24,6 +25,7 @@ bce_fwd_kernel(const float* __restrict__ p, int64_t ldp, const float* __restrict
     const float pv = p[i * ldp], yv = y[i * ldy];
     const float lp = fmaxf(logf(pv), -100.0f), l1p = fmaxf(logf(1.0f - pv), -100.0f);
     acc -= yv * lp + (1.0f - yv) * l1p;
+    if (gp1) gp1[i] = (pv - yv) / fmaxf((1.0f - pv) * pv, 1e-12f) * inv_n;  // bce_bwd_kernel with gloss = 1
   }
   acc = ctr_wave_sum(acc);
   if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
@@ -107,13 +109,14 @@ adam_kernel(const AdamPack P, float lr, float beta2, float omb1, float omb2, flo
 }  // namespace
 
 extern "C" int ctr_bce_fwd(const float* prob, int64_t ldp, const float* target, int64_t ldt, int64_t n, float* loss,
-                           float* workspace, int64_t workspace_floats, unsigned int* ticket, void* stream) {
+                           float* workspace, int64_t workspace_floats, unsigned int* ticket, float* gprob_unit,
+                           void* stream) {
   CTR_REQUIRE(n > 0 && prob && target && loss && workspace && ticket && ldp >= 1 && ldt >= 1, CTR_EINVAL);
   int64_t grid = ctr_ceil_div(n, kBlock * 4);
   if (grid > 256) grid = 256;
   CTR_REQUIRE(workspace_floats >= grid, CTR_ELIMIT);
   hipLaunchKernelGGL(bce_fwd_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, prob, ldp, target, ldt,
-                     n, 1.0f / (float)n, workspace, ticket, loss);
+                     n, 1.0f / (float)n, workspace, ticket, loss, gprob_unit);
   return ctr_launch_status();
 }
 

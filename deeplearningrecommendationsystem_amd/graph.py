@@ -37,7 +37,8 @@ class GraphedStep:
         model.zero_grad(set_to_none=True)
         # the root gradient of loss.backward() is a constant 1: made once here instead of by a fill
         # kernel inside every replay
-        self._one = torch.ones((), dtype=torch.float32, device=target.device)
+        from .loss import unit_grad  # BCELoss recognises this tensor and skips its scaling launch
+        self._one = unit_grad(target.device)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.prob = model(*self.inputs)

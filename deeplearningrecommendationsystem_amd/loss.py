@@ -26,6 +26,19 @@ def _ticket(device: torch.device) -> torch.Tensor:
     return t
 
 
+_units = {}
+
+
+def unit_grad(device: torch.device) -> torch.Tensor:
+    """THE scalar 1.0 of a device: pass it as ``loss.backward(unit_grad(dev))`` (GraphedStep does) and
+    BCELoss' backward recognises it by address and returns the gradient its forward launch already
+    wrote, instead of launching the scaling kernel.  Never write to it."""
+    t = _units.get(device.index)
+    if t is None:
+        t = _units[device.index] = torch.ones((), dtype=torch.float32, device=device)
+    return t
+
+
 class _BCEFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, prob, target):
@@ -35,17 +48,24 @@ class _BCEFunction(torch.autograd.Function):
             raise ValueError("BCELoss expects float32 input and target of the same size")
         loss = torch.empty((), dtype=torch.float32, device=prob.device)
         ws = torch.empty(256, dtype=torch.float32, device=prob.device)
+        # d loss / d prob for an upstream gradient of exactly 1, written by the same launch
+        gp1 = torch.empty(p.numel(), dtype=torch.float32, device=prob.device) if ctx.needs_input_grad[0] else None
         rc = _lib.load().ctr_bce_fwd(p.data_ptr(), p.stride(0) if p.numel() > 1 else 1, t.data_ptr(),
                                      t.stride(0) if t.numel() > 1 else 1, p.numel(), loss.data_ptr(),
-                                     ws.data_ptr(), ws.numel(), _ticket(prob.device).data_ptr(), _lib.stream_ptr())
+                                     ws.data_ptr(), ws.numel(), _ticket(prob.device).data_ptr(), _lib.ptr(gp1),
+                                     _lib.stream_ptr())
         _lib.check(rc, "ctr_bce_fwd")
         ctx.save_for_backward(p, t)
         ctx.shape = prob.shape
+        ctx.gp1 = gp1
         return loss
 
     @staticmethod
     def backward(ctx, gloss):
         p, t = ctx.saved_tensors
+        unit = _units.get(p.device.index)
+        if ctx.gp1 is not None and unit is not None and gloss.data_ptr() == unit.data_ptr():
+            return ctx.gp1.view(ctx.shape), None  # upstream gradient is THE 1.0: forward wrote this already
         gp = torch.empty(p.numel(), dtype=torch.float32, device=p.device)
         g = gloss.contiguous()
         rc = _lib.load().ctr_bce_bwd(p.data_ptr(), p.stride(0) if p.numel() > 1 else 1, t.data_ptr(),

@@ -377,9 +377,12 @@ int ctr_fold_head_bwd(const float* u_full, int p, const float* w, int64_t ldw, c
  * loss[0] = mean_i -[t_i*max(log p_i,-100) + (1-t_i)*max(log(1-p_i),-100)].
  * prob/target: element i at [i*ld]; workspace: >= 256 floats of device scratch; ticket: one device
  * word that is ZERO on entry and zero again when the call has run (the single launch finds its
- * last workgroup with it) -- allocate it once per stream, zeroed, and keep passing it. */
+ * last workgroup with it) -- allocate it once per stream, zeroed, and keep passing it.
+ * gprob_unit (nullable, n contiguous floats): receives what ctr_bce_bwd would write for gloss[0] == 1
+ * (bit-identical), so that a caller who knows its upstream gradient is 1 -- loss.backward() -- needs no
+ * second launch. */
 int ctr_bce_fwd(const float* prob, int64_t ldp, const float* target, int64_t ldt, int64_t n, float* loss,
-                float* workspace, int64_t workspace_floats, unsigned int* ticket, void* stream);
+                float* workspace, int64_t workspace_floats, unsigned int* ticket, float* gprob_unit, void* stream);
 /* gprob[i*ldg] = (p_i - t_i) / max(p_i (1-p_i), 1e-12) * gloss[0] / n */
 int ctr_bce_bwd(const float* prob, int64_t ldp, const float* target, int64_t ldt, int64_t n,
                 const float* gloss, float* gprob, int64_t ldg, void* stream);
