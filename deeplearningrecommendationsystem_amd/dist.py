@@ -43,8 +43,10 @@ class GradBucket:
                                                  if p.requires_grad and not getattr(p, "ctr_row_shard", False)]
         self._flat = None       # packing bucket, allocated on first use
         self._views = None
-        self._shared = {}       # storage data_ptr -> flat fp32 view of the whole storage
-        self._plan = None       # (key of the gradient tensors, storages) of the previous step
+        # (key of the gradient tensors, flat views of their storages) of the previous step.  The ONLY place a
+        # storage view outlives a call: kept when the gradients are static tensors (hipGraph replay) and
+        # small; a step with fresh gradient buffers replaces it, so at most one generation is ever pinned
+        self._plan = None
 
     def _pack_bucket(self):
         if self._flat is None:
@@ -69,11 +71,8 @@ class GradBucket:
             if key not in seen:
                 if len(seen) == self.MAX_STORAGES or st.nbytes() % 4:
                     return None
-                flat = self._shared.get(key)
-                if flat is None or flat.numel() != st.nbytes() // 4:
-                    flat = torch.empty(0, dtype=torch.float32, device=g.device).set_(st, 0, (st.nbytes() // 4,))
-                    self._shared[key] = flat
-                seen[key] = flat
+                # a fresh view per call: caching it here would pin every step's gradient buffer for good
+                seen[key] = torch.empty(0, dtype=torch.float32, device=g.device).set_(st, 0, (st.nbytes() // 4,))
         return list(seen.values())
 
     @staticmethod

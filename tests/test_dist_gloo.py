@@ -94,6 +94,24 @@ def _bucket_worker(rank, world, port, out):
         b.all_reduce_mean()
         torch.testing.assert_close(flat, torch.arange(16, dtype=torch.float32) * 1.5)
         assert ps[1].grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
+        # fresh gradient buffers every step (optimizer.zero_grad(set_to_none=True) + ops.zero_grads): the
+        # bucket must not keep any earlier step's storage alive (one flat buffer leaked per step)
+        import gc
+        import weakref
+        b = GradBucket(ps)
+        alive = []
+        for step in range(5):
+            flat = torch.full((16,), float(step + rank))
+            alive.append(weakref.ref(flat.untyped_storage()))  # the storage, not the tensor object
+            ps[0].grad, ps[1].grad, ps[2].grad = flat[0:4], flat[4:12], flat[12:15]
+            b.all_reduce_mean()
+            torch.testing.assert_close(flat, torch.full((16,), step + 0.5))
+            del flat
+        for q in ps:
+            q.grad = None
+        gc.collect()
+        held = sum(r() is not None for r in alive)
+        assert held <= 1, f"{held} gradient buffers still referenced by the bucket"  # at most the cached plan
         # many separately allocated gradients: packed into one bucket instead
         many = [torch.nn.Parameter(torch.zeros(2)) for _ in range(GradBucket.MAX_STORAGES + 2)]
         for i, q in enumerate(many):

@@ -427,5 +427,9 @@ def test_evaluator_matches_definitions():
     p = torch.tensor([0.9, 0.8, 0.4, 0.6, 0.2, 0.6])
     acc, prec, rec, f1, auc = Evaluator.eval(y, p)
     assert abs(acc - 3 / 6) < 1e-6 and abs(prec - 2 / 4) < 1e-6 and abs(rec - 2 / 3) < 1e-6
-    # pairs (pos, neg): 9 pairs; pos>neg: (.9: 3) + (.4: 1) + (.6: 1 + tie .5) = 5.5
-    assert abs(auc - 5.5 / 9) < 1e-6
+    # the reference feeds the THRESHOLDED predictions to roc_auc_score (evaluator/evaluator.py:17-19):
+    # hard = [1,1,0,1,0,1] -> TPR 2/3, TNR 1/3 -> 0.5
+    assert abs(auc - 0.5) < 1e-6
+    # the ranking AUC of the raw scores is the separately named extra.  9 (pos, neg) pairs;
+    # pos > neg: (.9: 3) + (.4: 1) + (.6: 1 + tie .5) = 5.5
+    assert abs(Evaluator.score_auc(y, p) - 5.5 / 9) < 1e-6
