@@ -52,6 +52,9 @@ WORKLOADS = {
     "nfm": "nfm hidden=[512,256,128,1] emb=128 ml-100k vocab batch=65536/gpu",
     "afm": "afm emb=128 attention=64 ml-100k vocab batch=65536/gpu",
     # the embedding stage alone at the roofline shape of SURVEY.md 8(d) cfg3b (metric ii: gather GB/s)
+    # BASELINE configs[2] as worded: the N-id-field generalisation of the two models
+    "deepfm26": "deepfm 26 id fields x 1e6 rows emb=16 hidden=[512,256,128,1] batch=65536/gpu (BASELINE configs[2] as worded)",
+    "pnn26": "pnn inner 26 id fields x 1e6 rows emb=16 hidden=[256,128,64,32] batch=65536/gpu (BASELINE configs[2] as worded)",
     "gather26": "embedding stage 26 fields x 1e6 rows x emb=16 batch=65536/gpu, uniform ids (gather fwd + dense-grad scatter bwd)",
     "gather26zipf": "embedding stage 26 fields x 1e6 rows x emb=16 batch=65536/gpu, Zipf(1.05) ids",
 }
@@ -70,12 +73,13 @@ def make_inputs(name: str, rank: int, batch: int):
     if name in ("din", "dien"):
         hist, target = synth.hist_batch(batch, 100, 10_000_000, gen)
         return [hist, target], synth.labels(batch, True, gen)
+    if name in ("deepfm26", "pnn26"):
+        return [torch.randint(0, 1_000_000, (batch, 26), generator=gen)], synth.labels(batch, True, gen)
     if name in ("gather26", "gather26zipf"):
         if name == "gather26":
             idx = torch.randint(0, 1_000_000, (batch, 26), generator=gen)
-        else:  # rank r of a Zipf(1.05) law over the 1e6 rows, by inverse-CDF on a log grid
-            u = torch.rand(batch, 26, generator=gen, dtype=torch.float64)
-            idx = ((1_000_000.0 ** u - 1.0)).long().clamp_(0, 999_999)  # alpha ~ 1: P(rank<=r) ~ log r / log V
+        else:
+            idx = zipf_ids(batch, 26, 1_000_000, gen)
         # the "target" is the gradient fed back into the stage (fixed, N(0,1))
         return [idx], torch.randn(batch, 26 * 16, generator=gen)
     raise SystemExit(f"unknown workload {name}")
@@ -119,6 +123,10 @@ def make_model(name: str, shard: bool = False):
         return zoo.AFM(943, 1682, 128, 64)                            # scripts/afm.py:52
     if name == "nfm":
         return zoo.NFM(943, 1682, [512, 256, 128, 1], 128)            # scripts/nfm.py:53
+    if name == "deepfm26":
+        return zoo.DeepFM(None, None, [512, 256, 128, 1], 16, num_fields=26, vocab=1_000_000)
+    if name == "pnn26":
+        return zoo.PNN(16, [256, 128, 64, 32], num_fields=26, vocab=1_000_000)
     if name in ("gather26", "gather26zipf"):
         return zoo.EmbeddingStage(26, 1_000_000, 16)
     raise SystemExit(f"unknown workload {name}")
@@ -145,7 +153,8 @@ def build_workload(name: str, device, rank: int, shard: bool = False, world: int
         inputs, y = make_inputs(name, rank, batch_of(name) // world)
         return m.to(device), [t.to(device) for t in inputs], y.to(device), WORKLOADS[name].replace(
             "single GPU", f"item table row-sharded over {world} rank(s), all-to-all lookup")
-    m = make_model(name)
+    with torch.device(device):  # parameters are created on the GPU (the 1e6..1e7-row tables take seconds on the host)
+        m = make_model(name)
     inputs, y = make_inputs(name, rank, batch_of(name))
     return m.to(device), [t.to(device) for t in inputs], y.to(device), WORKLOADS[name]
 
@@ -163,14 +172,22 @@ class _FeedGradient(torch.autograd.Function):
         return ctx.saved_tensors[0], None
 
 
+ORACLE_KEY = {"deepfm26": "deepfm_fields", "pnn26": "pnn_fields"}
+# workloads whose full batch takes the CPU minutes per step: the baseline runs a slice of the same batch
+CPU_SAMPLE_BATCH = {"din": 2048, "dien": 2048, "deepfm26": 16384, "pnn26": 16384, "deepfm": 16384}
+
+
 def cpu_baseline(name: str, model, budget_s: float = 15.0):
     """time the CPU oracle on the same workload (bounded sample), rank 0 only"""
     from oracle import ctr_oracle as orc  # checker/baseline only, never on the product path
     threads = min(16, os.cpu_count() or 1)  # the box's CPU share for one GPU
     torch.set_num_threads(threads)
-    batch = batch_of(name)
+    full = batch_of(name)
+    batch = CPU_SAMPLE_BATCH.get(name, full)
     params = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    inputs, y = make_inputs(name, 0, batch)
+    inputs, y = make_inputs(name, 0, full)
+    inputs, y = [t[:batch] for t in inputs], y[:batch]
+    name = ORACLE_KEY.get(name, name)
     orc.step(name, params, inputs, y)  # warm-up
     t0 = time.perf_counter()
     orc.step(name, params, inputs, y)
@@ -181,7 +198,9 @@ def cpu_baseline(name: str, model, budget_s: float = 15.0):
         orc.step(name, params, inputs, y)
     dt = (time.perf_counter() - t0) / reps
     return {"value": batch / dt, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} fwd+bwd steps of batch {batch} through oracle/ctr_oracle.py (torch CPU, fp32)",
+            "sample": f"{reps} fwd+bwd steps of batch {batch}" + ("" if batch == full else f" (the first {batch} samples of "
+                      f"the {full}-sample workload batch; the dense (V,E) gradients are built in full)") +
+                      " through oracle/ctr_oracle.py (torch CPU, fp32)",
             "ms_per_step": dt * 1e3}
 
 
@@ -195,6 +214,7 @@ def torch_gpu_baseline(name: str, model, device, steps: int = 20):
     params = {k: v.detach().to(device).clone() for k, v in model.state_dict().items()}
     inputs, y = make_inputs(name, 0, batch)
     inputs, y = [t.to(device) for t in inputs], y.to(device)
+    name = ORACLE_KEY.get(name, name)
     for _ in range(3):
         orc.step(name, params, inputs, y)
     torch.cuda.synchronize()
@@ -207,8 +227,92 @@ def torch_gpu_baseline(name: str, model, device, steps: int = 20):
             "what": f"{steps} eager fwd+bwd steps of batch {batch} through oracle/ctr_oracle.py on cuda (plain torch ops)"}
 
 
+def zipf_ids(batch: int, fields: int, vocab: int, gen) -> torch.Tensor:
+    """rank r of a Zipf(~1) law over the rows by inverse CDF on a log grid: P(rank <= r) = log r / log V"""
+    u = torch.rand(batch, fields, generator=gen, dtype=torch.float64)
+    return (float(vocab) ** u - 1.0).long().clamp_(0, vocab - 1)
+
+
+# dev/gather_ceiling.hip (profiles/r02_gather_ceiling_microbench.txt): random 64-B and 128-B rows of an
+# HBM-resident table are read at the SAME row rate (46.7 G rows/s = 6.0 TB/s of 128-B sectors), i.e. DRAM
+# serves 128 B per random request and a 64-B row uses half of it; reads and writes share the HBM bus
+# (copy time = read time + write time).  So one launch moves, on the DRAM side:
+DRAM_SECTOR = 128
+
+
+def gather_stage_leg(device, reps: int = 30):
+    """metric (ii): the fused embedding-stage kernels at the SURVEY 8(d) cfg3b roofline shape -- 26 id fields x
+    1e6 rows x E=16 (1.66 GB of tables, HBM-resident), batch 65536 -- timed in isolation: `reps` back-to-back
+    launches between two HIP events on the launch stream (torch's current stream), after 5 warm-up launches."""
+    from deeplearningrecommendationsystem_amd import _lib, ops
+    from deeplearningrecommendationsystem_amd._lib import FIELD_ID_I64
+    F, V, E, B = 26, 1_000_000, 16, BATCH
+    gen = torch.Generator().manual_seed(1234)
+    std = (2.0 / (V + E)) ** 0.5  # xavier_normal_ of a (V, E) table
+    tables = [torch.randn(V, E, device=device) * std for _ in range(F)]
+    grads = {id(t): torch.zeros_like(t) for t in tables}
+    out = torch.empty(B, F * E, device=device)
+    gout = torch.randn(B, F * E, device=device)
+    ws = torch.empty(ops.SCRATCH_FLOATS, dtype=torch.float32, device=device)
+    lib, st = _lib.load(), _lib.stream_ptr()
+    fwd_bytes = B * F * (E * 4 + 8 + E * 4)          # rows + int64 ids + output (SURVEY 8d: 3536 B/sample)
+    bwd_bytes = B * F * (E * 4 + 8 + 2 * E * 4)      # gout + ids + read-modify-write of each touched grad row
+    dram_fwd = B * F * (DRAM_SECTOR + 8 + E * 4)     # what DRAM moves for it at 128 B per random row
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e3 / reps
+
+    res = {}
+    for dist_name in ("uniform", "zipf"):
+        idx = (torch.randint(0, V, (B, F), generator=gen) if dist_name == "uniform" else zipf_ids(B, F, V, gen)).to(device)
+        specs = [ops.FieldSpec(FIELD_ID_I64, E, f * E, table=tables[f], idx=idx[:, f], idx_stride=F) for f in range(F)]
+        arr_f = ops._field_array(specs)
+        arr_b = ops._field_array(specs, grads)
+
+        def fwd():
+            _lib.check(lib.ctr_embed_fwd(arr_f, F, None, 0, B, out.data_ptr(), F * E, None, st), "ctr_embed_fwd")
+
+        def bwd():
+            _lib.check(lib.ctr_embed_bwd(arr_b, F, None, 0, B, gout.data_ptr(), F * E, ws.data_ptr(), ws.numel(), st),
+                       "ctr_embed_bwd")
+
+        t_f, t_b = timed(fwd), timed(bwd)
+        # parity on the spot: bit-exact rows (the last forward's output is still in `out`)
+        ref = torch.stack([tables[f][idx[:, f]] for f in range(F)], 1).view(B, F * E)
+        assert torch.equal(out, ref), "gather26 forward is not bit-exact"
+        res[dist_name] = {"fwd_us": t_f, "bwd_us": t_b, "fwd_gbs": fwd_bytes / t_f / 1e3, "bwd_gbs": bwd_bytes / t_b / 1e3}
+    u, z = res["uniform"], res["zipf"]
+    return {
+        "kernel": "embed_ids_fast_kernel", "bound": "hbm", "achieved": u["fwd_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": u["fwd_gbs"] / HBM_PEAK_GBS, "traffic": pmc_traffic("gather26", "embed_fwd_fast"), "avg_us": u["fwd_us"],
+        "algorithmic_bytes": fwd_bytes,
+        "workload": "SURVEY 8(d) cfg3b: 26 id fields x 1e6 rows x emb=16 (1.66 GB of tables), batch 65536, uniform ids, "
+                    f"{reps} back-to-back launches",
+        "dram_side": {"bytes": dram_fwd, "gbs": dram_fwd / u["fwd_us"] / 1e3, "frac_of_peak": dram_fwd / u["fwd_us"] / 1e3 / HBM_PEAK_GBS,
+                      "note": "random rows cost one 128-B DRAM sector each, whether 64 or 128 B are used "
+                              "(profiles/r02_gather_ceiling_microbench.txt): this is the rate the memory system sees"},
+        "zipf": {"avg_us": z["fwd_us"], "achieved": z["fwd_gbs"], "frac": z["fwd_gbs"] / HBM_PEAK_GBS,
+                 "what": "same launch, ids ~ Zipf(1): hot rows are served by L2 / Infinity Cache"},
+        "scatter_bwd": {"kernel": "embed_ids_fast_bwd_kernel", "bound": "atomic", "algorithmic_bytes": bwd_bytes,
+                        "uniform": {"avg_us": u["bwd_us"], "achieved": u["bwd_gbs"], "frac_of_hbm": u["bwd_gbs"] / HBM_PEAK_GBS,
+                                    "added_gbs": B * F * E * 4 / u["bwd_us"] / 1e3},
+                        "zipf": {"avg_us": z["bwd_us"], "achieved": z["bwd_gbs"], "added_gbs": B * F * E * 4 / z["bwd_us"] / 1e3},
+                        "atomic_peak_gbs": 1300.0,
+                        "note": "dense-grad scatter: fp32 atomics, ceiling ~1.3 TB/s of added bytes (MI355X_MICROARCH.md)"},
+    }
+
+
 # kernel label (ops.py) -> kernel name in the rocprofv3 / PMC summaries under profiles/
-KERNEL_NAMES = {"mlp_fused_bwd": "mlp_bwd_kernel", "mlp_fused_fwd": "mlp_fwd_kernel", "embed_fwd": "embed_fwd_kernel",
+KERNEL_NAMES = {"embed_fwd_fast": "embed_ids_fast_kernel", "mlp_fused_bwd": "mlp_bwd_kernel", "mlp_fused_fwd": "mlp_fwd_kernel", "embed_fwd": "embed_fwd_kernel",
                 "embed_bwd": "embed_bwd_kernel", "mf_fwd": "mf_fwd_kernel", "mf_bwd": "mf_bwd_kernel"}
 
 
@@ -262,7 +366,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="neuralcf")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather-leg", action="store_true", help="skip metric (ii): the cfg3b embedding-stage timing")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from Python instead of replaying a hipGraph")
+    ap.add_argument("--sparse", action="store_true", help="opt-in sparse mode of the big tables' gradients (SURVEY 8f-3): "
+                    "no dense zero-fill in backward, row-wise lazy Adam in full_step; NOT the reference's dense semantics")
     ap.add_argument("--shard", action="store_true", help="din / dien / ffm: row-shard the big id tables over the ranks "
                     "(all-to-all lookup, eager launches, global batch split over the ranks = strong scaling)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
@@ -299,6 +406,9 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group(args.backend, rank=0, world_size=1)
     model, inputs, y, desc = build_workload(args.workload, device, rank, args.shard, world)
+    if args.sparse:
+        model.sparse_grads(True)
+        desc += " [sparse-mode table gradients: opt-in, lazy row-wise Adam]"
     per_rank = inputs[0].shape[0]
     loss_fn = BCELoss()  # drop-in for torch.nn.BCELoss(), parity-tested against it
     if args.workload.startswith("gather26"):
@@ -374,6 +484,9 @@ def main():
     if world > 1:
         dist.barrier()
 
+    gather_leg = None
+    if rank == 0 and world == 1 and not args.no_gather_leg and not args.shard:
+        gather_leg = gather_stage_leg(device)
     if rank == 0:
         entries = {k: roofline_entry(k, v) for k, v in kernels.items()}
         dominant = max(kernels, key=lambda k: kernels[k]["total_us"])
@@ -394,24 +507,28 @@ def main():
             "loss": float(loss.item()), "launch": "eager" if args.no_graph else "hipGraph replay",
             "roofline": dict(entries[dominant], traffic=pmc_traffic(args.workload, dominant),
                              note=LABEL_NOTES.get(dominant)),
-            "gather_roofline": None if "embed_fwd" not in entries else
-            dict(entries["embed_fwd"], traffic=pmc_traffic(args.workload, "embed_fwd")),
+            # metric (ii) is defined on the HBM-resident cfg3b shape (gather_stage_leg); the step's own embedding
+            # kernel is reported under its own key -- for NeuralCF / ml-100k vocabularies its tables are cache-resident
+            "gather_roofline": gather_leg,
+            "step_embed_fwd": None if "embed_fwd" not in entries else
+            dict(entries["embed_fwd"], traffic=pmc_traffic(args.workload, "embed_fwd"),
+                 note="the timed step's embedding-stage launch; ml-100k-sized tables sit in L2 (cache-resident, "
+                      "not an HBM figure)" if args.workload in ("neuralcf", "mf", "pnn", "ffm", "deepcrossing") else None),
             "kernels": {k: {"avg_us": round(v["avg_us"], 2), "calls_per_step": v["calls"] / args.steps,
                             "bound": entries[k]["bound"], "frac": round(entries[k]["frac"], 4)}
                         for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["total_us"])},
             "gpu_kernel_us_per_step": round(kernel_us, 1),
             "full_step": None if full_ms is None else {
                 "ms_per_step": full_ms, "samples_per_s": per_rank / full_ms * 1e3,
-                "what": "zero_grad + forward + BCELoss + backward + Adam(lr=1e-3, weight_decay=1e-5).step()"},
+                "what": "zero_grad + forward + BCELoss + backward + Adam(lr=1e-3, weight_decay=1e-5).step()" +
+                        (" -- row-wise (lazy) on the sparse-mode tables" if args.sparse else "")},
         }
         if world == 1 and not args.no_cpu_baseline and not args.shard and not args.workload.startswith("gather26"):
             try:
                 out["torch_gpu_baseline"] = torch_gpu_baseline(args.workload, model, device)
             except Exception as exc:  # the oracle is CPU test infrastructure first: report, do not fail the bench
                 out["torch_gpu_baseline"] = {"error": repr(exc)[:200]}
-            # the CPU oracle only where a step takes seconds, not minutes (1e6..1e7-row tables, L = 100 histories)
-            if args.workload in ("neuralcf", "mf", "pnn", "ffm", "deepcrossing", "deepcross", "widedeep", "lr", "nfm", "afm"):
-                out["cpu_baseline"] = cpu_baseline(args.workload, model)
+            out["cpu_baseline"] = cpu_baseline(args.workload, model)
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (maps libamdhip64 first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTRHIP_LIB", os.path.join(_HERE, "libctrhip.so"))  # env override: A/B builds
-ABI_VERSION = 12
+ABI_VERSION = 14
 DIN_TRIPLE, DIN_PAIR = 0, 1  # layouts of the DIN attention operand (include/ctrhip.h)
 
 CTR_MAX_FIELDS = 32
@@ -61,6 +61,20 @@ class AdamTensor(C.Structure):
                 ("numel", C.c_int64)]
 
 
+class RowsMark(C.Structure):
+    """mirror of ``ctr_rows_mark_t``"""
+    _fields_ = [("ids", C.c_void_p), ("stride", C.c_int64), ("n", C.c_int64), ("vocab", C.c_int64),
+                ("flags", C.c_void_p), ("rows", C.c_void_p), ("count", C.c_void_p), ("ids_are_float", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class RowsTable(C.Structure):
+    """mirror of ``ctr_rows_table_t``"""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("flags", C.c_void_p), ("rows", C.c_void_p), ("count", C.c_void_p), ("done", C.c_void_p),
+                ("dim", C.c_int32), ("reserved", C.c_int32)]
+
+
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); must list every `ctr_*` symbol of include/ctrhip.h
@@ -79,6 +93,9 @@ SIGNATURES = {
     "ctr_fm_wide_fwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _p, _l, _p, _p]),
     "ctr_fm_wide_bwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _p, _l,
                              _p, _p, _p, _p, _p, _l, _i, _p, _l, _p]),
+    "ctr_fields_fm_fwd": (_i, [_p, _l, _l, _i, _i, C.POINTER(_p), C.POINTER(_l), C.POINTER(_p), _p, _p, _l, _p, _l, _p, _p]),
+    "ctr_fields_fm_bwd": (_i, [_p, _l, _l, _i, _i, C.POINTER(_l), _p, _l, _p, _l, _p, _l, C.POINTER(_p), C.POINTER(_p),
+                               _p, _p, _l, _p]),
     "ctr_ffm_head_fwd": (_i, [_p, _l, _l, _i, _i, C.POINTER(C.c_int32), _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l,
                               _p, _p, _p, _l, _p, _p]),
     "ctr_ffm_head_bwd": (_i, [_p, _l, _l, _i, _i, C.POINTER(C.c_int32), _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l,
@@ -105,6 +122,9 @@ SIGNATURES = {
     "ctr_fold_head_bwd": (_i, [_p, _i, _p, _l, _p, _i, _i, _p, _p, _p, _p, _l, _p, _p, _p]),
     "ctr_bce_fwd": (_i, [_p, _l, _p, _l, _l, _p, _p, _l, _p, _p, _p]),
     "ctr_bce_bwd": (_i, [_p, _l, _p, _l, _l, _p, _p, _l, _p]),
+    "ctr_rows_mark": (_i, [C.POINTER(RowsMark), _i, _p]),
+    "ctr_adam_rows": (_i, [C.POINTER(RowsTable), _i, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _l, _p]),
+    "ctr_rows_discard": (_i, [C.POINTER(RowsTable), _i, _p]),
     "ctr_adam_step": (_i, [C.POINTER(AdamTensor), _i, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _l, _p]),
 }
 

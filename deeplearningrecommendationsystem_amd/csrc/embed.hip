@@ -185,7 +185,7 @@ embed_bwd_kernel(const FieldPack P, int nfields, const float* __restrict__ x, in
         if (!f.grad) break;
         int64_t r = f.kind == CTR_FIELD_ID_I64 ? ctr_ldg(f.idx + (int64_t)b * f.idx_stride)
                                                 : (int64_t)x[(int64_t)b * ldx + f.src_col];
-        if (r < 0 || r >= f.vocab) r = 0;
+        if (r < 0 || r >= f.vocab) break;  // bad id: flagged by the forward, contributes to no row
         // Row 0 is the padding id of the behaviour sequences (scripts/din.py:23-31: a quarter of
         // a history is zeros): hundreds of thousands of same-address atomics would serialise
         // (~60 ns each).  It is summed per workgroup in LDS and flushed once.
@@ -209,8 +209,7 @@ embed_bwd_kernel(const FieldPack P, int nfields, const float* __restrict__ x, in
       default: {  // PROD: d(t1*t2) = g*t2, g*t1
         int64_t r1 = ctr_ldg(f.idx + (int64_t)b * f.idx_stride);
         int64_t r2 = ctr_ldg(f.idx2 + (int64_t)b * f.idx_stride);
-        if (r1 < 0 || r1 >= f.vocab) r1 = 0;
-        if (r2 < 0 || r2 >= f.vocab2) r2 = 0;
+        if (r1 < 0 || r1 >= f.vocab || r2 < 0 || r2 >= f.vocab2) break;  // bad id: no gradient
         const V t1 = ctr_ldg(reinterpret_cast<const V*>(f.table + r1 * f.width + off));
         const V t2 = ctr_ldg(reinterpret_cast<const V*>(f.table2 + r2 * f.width + off));
         if (f.grad) atomic_add_vec(f.grad + r1 * f.width + off, vmul(gv, t2));
@@ -322,15 +321,90 @@ bool try_fast_ids(const ctr_field_t* f, int n, int64_t batch, float* out, int64_
     T.vocab[i] = f[i].vocab;
   }
 #ifndef CTR_FAST_UNROLL
-#define CTR_FAST_UNROLL 4
+#define CTR_FAST_UNROLL 2  // A/B on MI355X (dev/gather_ab.py): 1/2/4/8 x grid caps are within 2 %, 2 x 8192 best on Zipf ids
 #endif
   constexpr int kUnroll = CTR_FAST_UNROLL;
   const uint32_t items = (uint32_t)(batch * n);
   const uint32_t per_block = (kBlock / lpr) * kUnroll;
   int64_t grid = ctr_ceil_div(items, per_block);
-  if (grid > 256 * 16) grid = 256 * 16;
+#ifndef CTR_FAST_GRID
+#define CTR_FAST_GRID (256 * 32)
+#endif
+  if (grid > CTR_FAST_GRID) grid = CTR_FAST_GRID;
   hipLaunchKernelGGL(embed_ids_fast_kernel<kUnroll>, dim3((unsigned)grid), dim3(kBlock), 0, st, T, n, lpr, w, f[0].idx,
                      items, out, ldo, err_flag, ctr_fastdiv((uint32_t)n));
+  *rc = ctr_launch_status();
+  return true;
+}
+
+// Backward of the same shape (F id fields of one width out of one (B,F) index matrix): the flat
+// element index g IS the offset into a dense gout, one dword per lane, so a wave-instruction adds to
+// 256/(4*width) whole gradient rows.  No descriptor LUT, no per-element struct copy: the generic
+// kernel spends ~20 LDS reads per element on those and runs at 0.4x the atomic rate on this shape
+// (239 us vs 94 us at 26 x 1e6 x 16, batch 65536; dev/gather_ceiling.hip has the bare loop).
+struct GradPtrs {
+  float* p[CTR_MAX_FIELDS];
+  int64_t vocab[CTR_MAX_FIELDS];
+};
+
+__global__ void __launch_bounds__(kBlock)
+embed_ids_fast_bwd_kernel(const GradPtrs G, int nfields, int wshift, const int64_t* __restrict__ idx, uint32_t items,
+                          const float* __restrict__ gout, int64_t ldo, const CtrFastDiv div) {
+  __shared__ float* s_grad[CTR_MAX_FIELDS];
+  __shared__ int64_t s_vocab[CTR_MAX_FIELDS];
+  extern __shared__ float s_row0[];  // [nfields][width]: row 0 (the sequences' padding id) summed per workgroup
+  if (threadIdx.x < nfields) {
+    s_grad[threadIdx.x] = G.p[threadIdx.x];
+    s_vocab[threadIdx.x] = G.vocab[threadIdx.x];
+  }
+  for (int i = threadIdx.x; i < (nfields << wshift); i += blockDim.x) s_row0[i] = 0.0f;
+  __syncthreads();
+  const uint32_t width = 1u << wshift;
+  const uint32_t total = items << wshift;  // < 2^32 (checked on the host)
+  bool any0 = false;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+    const uint32_t item = g >> wshift, e = g & (width - 1);
+    const uint32_t b = ctr_div(item, div);
+    const uint32_t f = item - b * div.d;
+    const int64_t r = ctr_ldg(idx + item);
+    const float v = ctr_ldg(gout + (int64_t)b * ldo + (f << wshift) + e);
+    float* dst = s_grad[f];
+    if (dst == nullptr || r < 0 || r >= s_vocab[f]) continue;  // frozen table / bad id: no gradient
+    if (r == 0) {  // same-address global atomics serialise (~60 ns each): see embed_bwd_kernel
+      atomicAdd(s_row0 + (f << wshift) + e, v);
+      any0 = true;
+    } else {
+      ctr_atomic_add_global(dst + (r << wshift) + e, v);
+    }
+  }
+  if (__syncthreads_or(any0)) {
+    for (int i = threadIdx.x; i < (nfields << wshift); i += blockDim.x) {
+      const float v = s_row0[i];
+      float* dst = s_grad[i >> wshift];
+      if (v != 0.0f && dst) ctr_atomic_add_global(dst + (i & (width - 1)), v);
+    }
+  }
+}
+
+bool try_fast_ids_bwd(const ctr_field_t* f, int n, int64_t batch, const float* gout, int64_t ldo, hipStream_t st,
+                      int* rc) {
+  const int w = f[0].width;
+  if (w <= 0 || w > 64 || (w & (w - 1)) != 0) return false;  // wider rows: the generic kernel's shape is fine
+  if (batch * n * w >= (1ll << 32)) return false;
+  GradPtrs G;
+  int wshift = 0;
+  while ((1 << wshift) < w) ++wshift;
+  for (int i = 0; i < n; ++i) {
+    if (f[i].kind != CTR_FIELD_ID_I64 || f[i].width != w || f[i].out_col != i * w) return false;
+    if (f[i].idx != f[0].idx + i || f[i].idx_stride != n) return false;
+    G.p[i] = f[i].grad;
+    G.vocab[i] = f[i].vocab;
+  }
+  const uint32_t items = (uint32_t)(batch * n);
+  const int grid = ctr_stream_grid((int64_t)items * w, kBlock);
+  hipLaunchKernelGGL(embed_ids_fast_bwd_kernel, dim3((unsigned)grid), dim3(kBlock), (size_t)n * w * sizeof(float), st, G, n,
+                     wshift, f[0].idx, items, gout, ldo, ctr_fastdiv((uint32_t)n));
   *rc = ctr_launch_status();
   return true;
 }
@@ -450,6 +524,11 @@ extern "C" int ctr_embed_bwd(const ctr_field_t* fields, int nfields, const float
                             handled, st);
   if (rc != CTR_OK) return rc;
   workspace_floats -= sort_floats;  // the sort buffers sit at the end
+  {  // nothing taken by the sorted path and every field an id column of one (B,F) matrix: the lean scatter
+    bool untouched = true;
+    for (int i = 0; i < nfields; ++i) untouched = untouched && !handled[i];
+    if (untouched && try_fast_ids_bwd(fields, nfields, batch, gout, ldo, st, &rc)) return rc;
+  }
   // bag tables: register accumulation per output column (embed_bag.hip), partials at the start
   rc = ctr_embed_bwd_bags(fields, nfields, x, ldx, batch, gout, ldo, workspace, workspace_floats, &bag_floats_used,
                           handled, st);

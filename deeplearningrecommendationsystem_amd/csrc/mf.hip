@@ -48,8 +48,7 @@ mf_bwd_kernel(const float* __restrict__ ut, int64_t nu, const float* __restrict_
   const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / group;
   for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / group; b < batch; b += groups) {
     int64_t u = uidx[b], i = iidx[b];
-    if (u < 0 || u >= nu) u = 0;
-    if (i < 0 || i >= ni) i = 0;
+    if (u < 0 || u >= nu || i < 0 || i >= ni) continue;  // bad id: flagged by the forward, no gradient
     const float p = prob[b];
     const float dz = gprob[b] * p * (1.0f - p);
     const float* up = ut + u * dim;

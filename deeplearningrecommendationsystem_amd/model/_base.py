@@ -7,16 +7,18 @@ import numpy as np
 import torch
 from torch import nn
 
-from .. import _lib
+from .. import _lib, sparse
 
 
 class CtrModule(nn.Module):
     """nn.Module whose forward/backward are libctrhip kernels.
 
-    Index validation: kernels never fault on a bad id (the row is read as row 0)
-    and raise a device flag; with ``CTRHIP_CHECK_INDEX=1`` (or
-    ``self.check_index = True``) the flag is read back after the forward and an
-    ``IndexError`` is raised like ``nn.Embedding`` does on CPU (costs a sync).
+    Index validation: kernels never fault on a bad id -- the forward reads it as row 0 and
+    raises a device flag, the backward adds its gradient to no row.  The flag is read where
+    the host syncs anyway: ``Trainer.model_eval`` (next to its ``loss.item()``), the sharded
+    lookup's count exchange, or ``check_bad_index()`` called by hand -- each raises the
+    ``IndexError`` ``nn.Embedding`` raises on CPU.  With ``CTRHIP_CHECK_INDEX=1`` (or
+    ``self.check_index = True``) it is read after every forward (one sync per call).
     """
 
     check_index = os.environ.get("CTRHIP_CHECK_INDEX", "0") == "1"
@@ -28,15 +30,51 @@ class CtrModule(nn.Module):
             object.__setattr__(self, "_err", flag)
         return flag
 
+    def check_bad_index(self):
+        """read the device flag (one sync) and raise IndexError if any lookup since the last check saw an
+        id outside its table"""
+        flag = getattr(self, "_err", None)
+        if flag is not None and int(flag.item()) != 0:
+            flag.zero_()
+            raise IndexError("index out of range in self")
+
     def _raise_if_bad_index(self):
-        if self.check_index and getattr(self, "_err", None) is not None:
-            if int(self._err.item()) != 0:
-                self._err.zero_()
-                raise IndexError("index out of range in self")
+        if self.check_index:
+            self.check_bad_index()
 
     @staticmethod
     def _need_device(*tensors):
         _lib.require_device(*tensors)
+
+    # ---- opt-in sparse mode of the big tables' gradients (sparse.py; SURVEY 8f-3)
+    def sparse_ids(self, inputs):
+        """{position in the autograd node's parameter list: [id tensors scattered into that table]} -- models
+        whose tables can run in sparse mode override this"""
+        return {}
+
+    def _node_params(self):
+        return self._params()
+
+    def sparse_grads(self, enable: bool = True, min_rows: int = 65536):
+        """switch the tables with at least ``min_rows`` rows to the sparse gradient mode (or back).  Call after the
+        module is on its device; train with ``deeplearningrecommendationsystem_amd.optim.Adam`` (it updates the
+        pending rows; a stock torch optimizer would see ``grad is None`` and skip these tables)."""
+        params = self._node_params()
+        positions = sorted(self.sparse_ids(None))
+        if enable and not positions:
+            raise NotImplementedError(f"{type(self).__name__} has no sparse-mode tables")
+        for k in positions:
+            p = params[k]
+            if enable and p.shape[0] >= min_rows:
+                if sparse.state_of(p) is None:
+                    p._ctr_sparse = sparse.SparseRows(p)
+            elif sparse.state_of(p) is not None:
+                del p._ctr_sparse
+        return self
+
+    def zero_grad(self, set_to_none: bool = True):
+        super().zero_grad(set_to_none)
+        sparse.discard(self.parameters())
 
 
 def topk_rows(scores: torch.Tensor, k: int) -> np.ndarray:
@@ -63,6 +101,16 @@ class _ModelFunction(torch.autograd.Function):
         inputs, params = tensors[:ctx.n_inputs], tensors[ctx.n_inputs:]
         grads = ctx.impl.run_backward(ctx.state, inputs, params, gout.contiguous())
         ctx.state = None
+        if any(sparse.state_of(p) is not None for p in params):
+            # sparse mode: the scatter went into the tables' persistent buffers; list the rows it touched and
+            # hand autograd no dense gradient for those tables
+            grads = list(grads)
+            jobs = []
+            for k, id_list in ctx.impl.sparse_ids(inputs).items():
+                if sparse.state_of(params[k]) is not None:
+                    jobs += [(params[k], ids) for ids in id_list]
+                    grads[k] = None
+            sparse.mark(jobs)
         return (None, None) + (None,) * ctx.n_inputs + tuple(grads)
 
 
@@ -76,6 +124,14 @@ class FeatureModel(CtrModule):
         x = x if x.stride(1) == 1 else x.contiguous()
         object.__setattr__(self, "_flag", self._err_flag(x.device))
         out = _ModelFunction.apply(self, 1, x, *params)
+        self._raise_if_bad_index()
+        return out
+
+    def _run_fields(self, idx, params):
+        """N-id-field generalisation: ``idx`` (B, F) int64 on the device"""
+        self._need_device(idx, params[0])
+        object.__setattr__(self, "_flag", self._err_flag(idx.device))
+        out = _ModelFunction.apply(self, 1, idx, *params)
         self._raise_if_bad_index()
         return out
 

@@ -63,6 +63,12 @@ class SequenceModel(CtrModule):
         from ..dist import ShardedEmbedding
         return ShardedEmbedding(num_items, embed_size, group=group)
 
+    def sparse_ids(self, inputs):
+        """sparse mode: the item table (position 0) is touched by every history id and the target ids"""
+        if getattr(self, "sharded", False):
+            return {}
+        return {0: [] if inputs is None else [inputs[0].reshape(-1), inputs[1]]}
+
     def _lookup_sharded(self, table_module, hist, target):
         """rows of every (hist, target) id through the all-to-all exchange, then the model runs
         on them as if they were a (B*L+B)-row table indexed 0..B*L+B-1: the kernels are unchanged,

@@ -32,6 +32,14 @@ class EmbeddingStage(CtrModule):
         f, e = self.num_fields, self.dim
         return [FieldSpec(FIELD_ID_I64, e, k * e, table=tables[k], idx=idx[:, k], idx_stride=f) for k in range(f)]
 
+    def _node_params(self):
+        return list(self.tables)
+
+    def sparse_ids(self, inputs):
+        if inputs is None:
+            return {k: [] for k in range(self.num_fields)}
+        return {k: [inputs[0][:, k]] for k in range(self.num_fields)}
+
     def run_forward(self, inputs, params):
         (idx,) = inputs
         out = torch.empty((idx.shape[0], self.num_fields * self.dim), dtype=torch.float32, device=params[0].device)

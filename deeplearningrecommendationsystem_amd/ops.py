@@ -304,10 +304,24 @@ def zero_grads(tensors: Sequence[torch.Tensor]) -> dict:
     """{id(t): zero tensor shaped like t} for every parameter of a backward pass, carved
     out of ONE flat buffer so a step issues a single memset instead of one per
     parameter (each piece starts 16-byte aligned)."""
-    sizes = [(t.numel() + 3) // 4 * 4 for t in tensors]
-    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=tensors[0].device)
-    out, off = {}, 0
-    for t, n in zip(tensors, sizes):
+    out = {}
+    dense = []
+    for t in tensors:
+        st = getattr(t, "_ctr_sparse", None)
+        if st is None:
+            dense.append(t)
+            continue
+        # sparse mode (sparse.py): the table's persistent accumulation buffer, clean outside pending rows --
+        # the scatter kernels add into it as they would into a fresh zero buffer, nothing is zero-filled
+        if st.grad.device != t.device or st.grad.shape != t.shape:
+            raise RuntimeError("sparse-mode state does not match its table (enable sparse_grads after .to(device))")
+        out[id(t)] = st.grad
+    if not dense:
+        return out
+    sizes = [(t.numel() + 3) // 4 * 4 for t in dense]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dense[0].device)
+    off = 0
+    for t, n in zip(dense, sizes):
         out[id(t)] = flat[off:off + t.numel()].view(t.shape)
         off += n
     return out
@@ -582,6 +596,48 @@ def fm_wide_bwd(emb, nvec, dim, x, user1, item1, wide_w, wide_b, gout, guser1, g
                 _lib.ptr(gitem1), _lib.ptr(gwide_w), _lib.ptr(gwide_b), _lib.ptr(gemb),
                 _ld(gemb) if gemb is not None else 0, int(accumulate), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
     _lib.check(rc, "ctr_fm_wide_bwd")
+
+
+def _ptr_array(tensors):
+    """host array of device pointers (NULL for None); None -> NULL array"""
+    if tensors is None:
+        return None
+    return (C.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def fields_fm_fwd(idx, tables, first, bias, emb, fm, err_flag=None) -> None:
+    """N id fields: gather into ``emb`` (B, F*E) + FM second order + first-order sum into ``fm`` (B,1) -- one launch"""
+    _lib.require_device(idx, emb, fm, *tables)
+    emb, fm = _mat(emb, "emb"), _mat(fm, "fm")
+    if idx.dtype != torch.int64 or idx.dim() != 2 or idx.stride(1) != 1:
+        raise ValueError("fields_fm_fwd: idx must be a (B,F) int64 matrix with unit inner stride")
+    batch, nf = idx.shape
+    dim = tables[0].shape[1]
+    vocabs = (C.c_int64 * nf)(*[t.shape[0] for t in tables])
+    n1 = 0 if first is None else sum(1 for t in first if t is not None)
+    rc = _timed("fields_fm_fwd", lambda: (batch * (nf * (dim * 8 + 8) + 4 * n1 + 4), 4 * batch * nf * dim),
+                _lib.load().ctr_fields_fm_fwd, idx.data_ptr(), idx.stride(0), batch, nf, dim, _ptr_array(tables), vocabs,
+                _ptr_array(first), _lib.ptr(bias), emb.data_ptr(), _ld(emb), fm.data_ptr(), _ld(fm),
+                _lib.ptr(err_flag), _lib.stream_ptr())
+    _lib.check(rc, "ctr_fields_fm_fwd")
+
+
+def fields_fm_bwd(idx, vocabs, dim, emb, gdeep, gfm, gtables, gfirst, gbias) -> None:
+    """backward of ``fields_fm_fwd``: scatter-add ``gdeep + gfm * (S - v)`` into the dense table gradients"""
+    emb = _mat(emb, "emb")
+    batch, nf = idx.shape
+    gdeep = _mat(gdeep, "gdeep") if gdeep is not None else None
+    gfm = _mat(gfm, "gfm") if gfm is not None else None
+    ws = _scratch(emb.device) if gbias is not None else None
+    n1 = 0 if gfirst is None else sum(1 for t in gfirst if t is not None)
+    rc = _timed("fields_fm_bwd", lambda: (batch * (nf * (dim * 4 * (2 + (gdeep is not None)) + 8) + 8 * n1 + 4),
+                                          3 * batch * nf * dim),
+                _lib.load().ctr_fields_fm_bwd, idx.data_ptr(), idx.stride(0), batch, nf, dim,
+                (C.c_int64 * nf)(*vocabs), emb.data_ptr(), _ld(emb), _lib.ptr(gdeep),
+                _ld(gdeep) if gdeep is not None else 0, _lib.ptr(gfm), _ld(gfm) if gfm is not None else 0,
+                _ptr_array(gtables), _ptr_array(gfirst), _lib.ptr(gbias), _lib.ptr(ws),
+                ws.numel() if ws is not None else 0, _lib.stream_ptr())
+    _lib.check(rc, "ctr_fields_fm_bwd")
 
 
 def _pair_array(pairs):

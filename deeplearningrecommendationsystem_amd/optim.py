@@ -8,7 +8,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, sparse
 
 
 class Adam(torch.optim.Optimizer):
@@ -26,8 +26,21 @@ class Adam(torch.optim.Optimizer):
         lib = _lib.load()
         for group in self.param_groups:
             todo = []
+            rows = []   # tables in sparse mode (sparse.py): Adam on their pending rows only
             step = None
             for p in group["params"]:
+                if sparse.state_of(p) is not None:
+                    st = self.state[p]
+                    if not st:
+                        st["step"] = 0
+                        st["exp_avg"] = torch.zeros_like(p)
+                        st["exp_avg_sq"] = torch.zeros_like(p)
+                    st["step"] += 1
+                    step = st["step"] if step is None else step
+                    if st["step"] != step:
+                        raise RuntimeError("parameters of one group must share a step count")
+                    rows.append((p, st["exp_avg"], st["exp_avg_sq"]))
+                    continue
                 if p.grad is None:
                     continue
                 _lib.require_device(p)
@@ -43,6 +56,8 @@ class Adam(torch.optim.Optimizer):
                 if st["step"] != step:
                     raise RuntimeError("parameters of one group must share a step count")
                 todo.append((p, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"]))
+            if rows:
+                sparse.adam_rows(rows, group["lr"], group["betas"], group["eps"], group["weight_decay"], step)
             if not todo:
                 continue
             arr = (_lib.AdamTensor * len(todo))()
@@ -53,3 +68,8 @@ class Adam(torch.optim.Optimizer):
                                    group["weight_decay"], step, _lib.stream_ptr())
             _lib.check(rc, "ctr_adam_step")
         return loss
+
+    def zero_grad(self, set_to_none: bool = True):
+        """also drops the pending gradient rows of tables in sparse mode"""
+        super().zero_grad(set_to_none)
+        sparse.discard(p for group in self.param_groups for p in group["params"])

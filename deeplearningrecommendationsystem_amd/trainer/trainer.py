@@ -90,6 +90,11 @@ class Trainer:
 
     def model_eval(self, epoch):
         """prints the reference's per-epoch report (trainer/trainer.py:116-146)"""
+        # the report syncs on loss.item() anyway: the place to surface a bad id seen by any step since the
+        # last report (the HIP modules flag it on the device instead of asserting like nn.Embedding)
+        check = getattr(self.model, "check_bad_index", None)
+        if check is not None:
+            check()
         ev = Evaluator()
         tr = ev.eval(self.train_rating, self.predictions_train)
         va = ev.eval(self.valid_rating, self.predictions_valid)

@@ -89,6 +89,62 @@ rows_kernel(const float* __restrict__ tab, int64_t V, int E, int F, const IdxT* 
   if (MODE == 1 && acc.x + acc.y + acc.z + acc.w == -12345.678f) sink[threadIdx.x] = acc.x;
 }
 
+// the same copy with the row loads issued from inline asm so that the cache-policy bits can be chosen:
+// POLICY 0 plain, 1 nt, 2 sc0, 3 sc1, 4 sc0 sc1, 5 sc0 sc1 nt.  Question: does any policy make the L2 fetch 64 B
+// (TCC_EA0_RDREQ_64B) instead of a whole 128-B line for a 64-B row?
+template <int POLICY>
+__device__ __forceinline__ f32x4 policy_load(const float* p) {
+  f32x4 v;
+  if (POLICY == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  if (POLICY == 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+  if (POLICY == 2) asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
+  if (POLICY == 3) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  if (POLICY == 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+  if (POLICY == 5) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+template <int POLICY, bool COPY>
+__global__ void __launch_bounds__(kBlock)
+policy_kernel(const float* __restrict__ tab, int64_t V, int E, int F, const int64_t* __restrict__ idx, uint32_t items,
+              float* __restrict__ out, float* __restrict__ sink) {
+  constexpr int UNROLL = 2;
+  const int lpr = E / 4;
+  const int sub = threadIdx.x % lpr;
+  const uint32_t rpb = kBlock / lpr;
+  const uint32_t per_block = rpb * UNROLL;
+  const uint32_t slot = threadIdx.x / lpr;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (uint32_t base = blockIdx.x * per_block; base < items; base += gridDim.x * per_block) {
+    const float* src[UNROLL];
+    float* dst[UNROLL];
+    bool live[UNROLL];
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k) {
+      const uint32_t i = base + slot + k * rpb;
+      live[k] = i < items;
+      const uint32_t ii = live[k] ? i : 0;
+      const uint32_t f = ii % (uint32_t)F;
+      src[k] = tab + ((int64_t)f * V + idx[ii]) * E + sub * 4;
+      dst[k] = out + (int64_t)ii * E + sub * 4;
+    }
+    f32x4 v[UNROLL];
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k) v[k] = policy_load<POLICY>(src[k]);
+    // the wait takes the loaded registers as in/out operands: no use of them can be scheduled above it
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]) : : "memory");
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k) {
+      if (COPY) {
+        if (live[k]) *(GLOBAL f32x4*)(dst[k]) = v[k];
+      } else {
+        acc += v[k];
+      }
+    }
+  }
+  if (!COPY && acc.x + acc.y + acc.z + acc.w == -12345.678f) sink[threadIdx.x] = acc.x;
+}
+
 // scatter-add of gout rows into grad rows: one dword per lane (16 lanes per 64-B row)
 template <bool ATOMIC, typename IdxT>
 __global__ void __launch_bounds__(kBlock)
@@ -134,7 +190,8 @@ struct Timer {
 };
 
 int main(int argc, char** argv) {
-  const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+  const bool quick = argc > 1 && (!strcmp(argv[1], "quick") || !strcmp(argv[1], "policy"));
+  const bool policy_only = argc > 1 && !strcmp(argv[1], "policy");
   const int F = 26, B = 65536;
   const uint32_t items = (uint32_t)F * B;
   Timer T;
@@ -222,9 +279,20 @@ int main(int argc, char** argv) {
           return (int)std::min<int64_t>(g, cap);
         };
         const double copy_b = items * (2 * row_b + 8), read_b = items * (row_b + 8), write_b = items * row_b;
+#define POL(P) \
+  report("policy" #P " read", T.us([&] { policy_kernel<P, false><<<8192, kBlock>>>(tab, V, E, F, idx, items, out, sink); }, reps), read_b); \
+  report("policy" #P " copy", T.us([&] { policy_kernel<P, true><<<8192, kBlock>>>(tab, V, E, F, idx, items, out, sink); }, reps), copy_b);
 #define RUN(UNR, MODE, PERMF, IDX, PERM, FIELD, CAP) \
   T.us([&] { rows_kernel<UNR, MODE, PERMF><<<grid_for(UNR, CAP), kBlock>>>(tab, V, E, F, IDX, PERM, FIELD, items, out, sink); }, reps)
         report("copy u4 g4096", RUN(4, 0, false, idx, nullptr, nullptr, 4096), copy_b);
+        if (policy_only) {
+          report("copy u2 g8192", RUN(2, 0, false, idx, nullptr, nullptr, 8192), copy_b);
+          report("read u2 g8192", RUN(2, 1, false, idx, nullptr, nullptr, 8192), read_b);
+          POL(0) POL(1) POL(2) POL(3) POL(4) POL(5)
+          CK(hipFree(idx)); CK(hipFree(sidx)); CK(hipFree(sidx2)); CK(hipFree(idx32));
+          CK(hipFree(perm)); CK(hipFree(field)); CK(hipFree(perm2)); CK(hipFree(field2));
+          continue;
+        }
         if (!quick || true) {
           report("copy u1 g8192", RUN(1, 0, false, idx, nullptr, nullptr, 8192), copy_b);
           report("copy u2 g8192", RUN(2, 0, false, idx, nullptr, nullptr, 8192), copy_b);

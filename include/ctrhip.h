@@ -166,6 +166,29 @@ int ctr_pairprod_bwd(const float* emb, int64_t lde, int64_t batch, int nvec, int
                      const float* gpool /*nullable*/, int64_t ldgo,
                      float* gemb, int64_t ldg, int accumulate, void* stream);
 
+/* N single-id fields, gather fused with the FM interaction (model/deepfm.py:45-46 applied to each of
+ * F id columns, :63 first-order id terms, :71-77 second order; BASELINE configs[2] "26 fields x 1e6
+ * vocab").  idx is the (batch, >= nfields) int64 id matrix (row stride ldidx); tables[f] is the
+ * (vocabs[f], dim) table of field f, first[f] its (vocabs[f], 1) first-order weight (first or any
+ * first[f] may be NULL); host arrays of device pointers.  dim in {8, 16, 32, 64}.
+ *   emb[b, f*dim + e] = tables[f][idx[b,f], e]                       (bit-exact row copies)
+ *   fm[b*ldfm] = (sum_f first[f][idx[b,f]] + bias[0]) + 0.5 * sum_e[(sum_f v_fe)^2 - sum_f v_fe^2]
+ * A bad id reads row 0 and raises *err_flag (nullable). */
+int ctr_fields_fm_fwd(const int64_t* idx, int64_t ldidx, int64_t batch, int nfields, int dim,
+                      const float* const* tables, const int64_t* vocabs, const float* const* first /*nullable*/,
+                      const float* bias /*nullable*/, float* emb, int64_t lde, float* fm, int64_t ldfm,
+                      int32_t* err_flag, void* stream);
+/* backward of the above for g = gfm[b*ldgfm] and the gradient gdeep (batch, nfields*dim) that the
+ * consumers of emb returned (either may be NULL): dense scatter-add with fp32 atomics
+ *   gtables[f][idx[b,f], e] += gdeep[b, f*dim+e] + g * (S_e - v_fe)   (v read back from emb, S_e = sum_f v_fe)
+ *   gfirst[f][idx[b,f]] += g,   gbias[0] += sum_b g   (fixed-order partials through the workspace)
+ * gtables[f] / gfirst / gfirst[f] / gbias may be NULL (frozen). */
+int ctr_fields_fm_bwd(const int64_t* idx, int64_t ldidx, int64_t batch, int nfields, int dim, const int64_t* vocabs,
+                      const float* emb, int64_t lde, const float* gdeep /*nullable*/, int64_t ldg,
+                      const float* gfm /*nullable*/, int64_t ldgfm, float* const* gtables,
+                      float* const* gfirst /*nullable*/, float* gbias /*nullable*/, float* workspace,
+                      int64_t workspace_floats, void* stream);
+
 /* DeepFM wide part + FM second order (model/deepfm.py:63,71-77):
  *   out[b*ldo] = user1[u] + item1[i] + (x[b, dense_col0..+ndense) . wide_w + wide_b)
  *               + 0.5 * sum_e[(sum_f v_fe)^2 - sum_f v_fe^2]
@@ -386,6 +409,47 @@ int ctr_bce_fwd(const float* prob, int64_t ldp, const float* target, int64_t ldt
 /* gprob[i*ldg] = (p_i - t_i) / max(p_i (1-p_i), 1e-12) * gloss[0] / n */
 int ctr_bce_bwd(const float* prob, int64_t ldp, const float* target, int64_t ldt, int64_t n,
                 const float* gloss, float* gprob, int64_t ldg, void* stream);
+
+/* ---- opt-in sparse mode of the embedding gradient / optimizer (replaces, for the rows a
+ * batch touches, what `optim.Adam(model.parameters(), lr, weight_decay=1e-5)` does to whole tables:
+ * scripts/din.py:87, trainer/trainer.py:39).  A table in sparse mode owns persistent device state: a
+ * (vocab, dim) gradient accumulation buffer that is all-zero outside pending rows, one int32 flag per row
+ * (0 = clean), an int32 list of pending rows (capacity vocab) with its length, and a ticket word. */
+typedef struct ctr_rows_mark_t {
+  const void* ids;       /* the ids the backward just scattered: int64, or float32 (ids_are_float) */
+  int64_t stride;        /* elements between consecutive ids (a column of a (B,F) matrix: F) */
+  int64_t n;             /* number of ids */
+  int64_t vocab;         /* rows of the table (< 2^31); ids outside [0, vocab) are skipped */
+  int32_t* flags;        /* [vocab] */
+  int32_t* rows;         /* [vocab] pending-row list */
+  int32_t* count;        /* [1] its length */
+  int32_t ids_are_float;
+  int32_t reserved;
+} ctr_rows_mark_t;
+
+typedef struct ctr_rows_table_t {
+  float* param;          /* (vocab, dim); NULL allowed for ctr_rows_discard */
+  float* grad;           /* (vocab, dim) persistent accumulation buffer */
+  float* exp_avg;
+  float* exp_avg_sq;
+  int32_t* flags;
+  int32_t* rows;
+  int32_t* count;
+  uint32_t* done;        /* [1] zero-initialised ticket */
+  int32_t dim;
+  int32_t reserved;
+} ctr_rows_table_t;
+
+/* after the scatter kernels have added a batch's gradient rows into `grad`: append every row touched for the
+ * first time since the last ctr_adam_rows / ctr_rows_discard to the table's pending list.  One job per
+ * (table, id list); several jobs may name the same table.  njobs <= CTR_MAX_FIELDS. */
+int ctr_rows_mark(const ctr_rows_mark_t* jobs, int njobs, void* stream);
+/* Adam on the pending rows only (same update rule as ctr_adam_step, L2 added to the gradient of those rows),
+ * then grad rows, flags and the list are left clean.  `step` = this parameter's 1-based step count. */
+int ctr_adam_rows(const ctr_rows_table_t* tables, int ntables, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, int64_t step, void* stream);
+/* drop the pending gradient rows (what zero_grad means in sparse mode) */
+int ctr_rows_discard(const ctr_rows_table_t* tables, int ntables, void* stream);
 
 /* torch.optim.Adam(params, lr, betas, eps, weight_decay) (e.g. scripts/pnn.py:55), one
  * step over all tensors in one launch (16-byte aligned, contiguous fp32):

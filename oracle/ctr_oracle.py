@@ -331,6 +331,50 @@ def deepfm_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
     return torch.sigmoid(_lin(p, "output", torch.cat([wide, h], dim=1)))
 
 
+# --------------------------------------------------------------------------
+# generalised N-field DeepFM / PNN (BASELINE configs[2]: "26 fields x 1e6 vocab").  The reference hard-codes six
+# fields (model/deepfm.py:14-17, model/pnn.py:87-92); these restate the SAME forward with the six vectors replaced
+# by F single-id lookups ``embeddings.f[x[:, f].long()]`` -- the pattern of deepfm.py:45-46 / pnn.py:113-114 applied
+# to every column -- and everything downstream unchanged, built from the same pinned pieces (_emb, _lin,
+# fm_second_order, pnn_inner_products).  The reference cannot build such a model, so no reference fixture exists
+# at F != 6; the restatements are pinned THROUGH the pinned six-field oracle instead
+# (tests/test_oracle_golden.py::test_*_fields_oracle_reduces_to_the_pinned_six_field_oracle: with the bag tables
+# zeroed the reference model is a two-id-field model padded with zero vectors, which the F = 6 restatement must
+# reproduce on the reference fixture's own parameters: outputs, loss, gradients).
+# --------------------------------------------------------------------------
+def field_vectors(p: Params, x: torch.Tensor) -> Sequence[torch.Tensor]:
+    """F id lookups: column f of ``x`` (ids as floats or int64) into ``embeddings.f``"""
+    n = _count(p, "embeddings")
+    ids = x if not x.is_floating_point() else None
+    return [_emb(p, f"embeddings.{f}", ids[:, f] if ids is not None else ids_from_float(x[:, f])) for f in range(n)]
+
+
+def deepfm_fields_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
+    """model/deepfm.py:43-83 over F id fields: first order = sum_f first_order.f[id_f] + first_order_bias (the
+    id terms of deepfm.py:63; with no dense columns the ``wide`` Linear reduces to its bias)"""
+    f = field_vectors(p, x)
+    h = _lin(p, "linear", torch.cat(f, dim=1))
+    for k in range(_count(p, "dnn_network")):
+        h = torch.relu(_lin(p, f"dnn_network.{k}", h))
+    ids = x if not x.is_floating_point() else torch.stack([ids_from_float(x[:, c]) for c in range(x.shape[1])], 1)
+    wide = _emb(p, "first_order.0", ids[:, 0])
+    for c in range(1, len(f)):
+        wide = wide + _emb(p, f"first_order.{c}", ids[:, c])
+    wide = wide + p["first_order_bias"]
+    wide = wide + fm_second_order(f).unsqueeze(1)
+    return torch.sigmoid(_lin(p, "output", torch.cat([wide, h], dim=1)))
+
+
+def pnn_fields_forward(p: Params, x: torch.Tensor) -> torch.Tensor:
+    """model/pnn.py:111-131 (inner mode) over F id fields: F(F-1)/2 inner products, i<j lexicographic"""
+    f = field_vectors(p, x)
+    z = torch.cat(f, dim=1).unsqueeze(0)
+    h = _lin(p, "product.linear1", z) + _lin(p, "product.linear2", pnn_inner_products(f))
+    for k in range(_count(p, "dnn.dnn_network")):
+        h = torch.relu(_lin(p, f"dnn.dnn_network.{k}", h))
+    return torch.sigmoid(_lin(p, "output", h)).view(-1, 1)
+
+
 def din_attention(p: Params, prefix: str, hist: torch.Tensor, target: torch.Tensor):
     """model/din.py:35-44 / model/dien.py:25-34: returns (H, t, a) with
     a = softmax over L of MLP([h, h-t, t]); no padding mask (pad id 0 is a
@@ -393,10 +437,26 @@ def bce_loss(prob: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     return -(y * lp + (1.0 - y) * l1p).mean()
 
 
+def adam_update(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int, lr: float = 1e-3,
+                betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, rows: torch.Tensor = None) -> None:
+    """``torch.optim.Adam`` (no amsgrad) restated, in place: the update every reference script applies
+    (``optim.Adam(model.parameters(), lr, weight_decay=1e-5)``, e.g. scripts/pnn.py:55).  With ``rows`` it is the
+    LAZY row-wise rule of the build's opt-in sparse mode: only the listed rows are decayed and
+    updated, with the parameter's global step count in the bias corrections; every other row of p, m, v is
+    untouched.  Not a reference semantics: pinned by construction (same formula on a row subset)."""
+    b1, b2 = betas
+    sel = slice(None) if rows is None else rows
+    gr = g[sel] + weight_decay * p[sel]
+    m[sel] = m[sel] + (1.0 - b1) * (gr - m[sel])
+    v[sel] = v[sel] * b2 + (1.0 - b2) * gr * gr
+    bc1, bc2 = 1.0 - b1 ** step, 1.0 - b2 ** step
+    p[sel] = p[sel] - (lr / bc1) * (m[sel] / (v[sel].sqrt() / bc2 ** 0.5 + eps))
+
+
 FORWARDS: Dict[str, Callable[..., torch.Tensor]] = {
     "mf": mf_forward, "neuralcf": neuralcf_forward, "ffm": ffm_forward, "pnn": pnn_forward,
     "deepcrossing": deepcrossing_forward, "deepfm": deepfm_forward, "din": din_forward,
-    "dien": dien_forward, "deepcross": deepcross_forward, "widedeep": widedeep_forward, "lr": lr_forward, "nfm": nfm_forward, "afm": afm_forward, "autorec": autorec_forward,
+    "dien": dien_forward, "deepfm_fields": deepfm_fields_forward, "pnn_fields": pnn_fields_forward, "deepcross": deepcross_forward, "widedeep": widedeep_forward, "lr": lr_forward, "nfm": nfm_forward, "afm": afm_forward, "autorec": autorec_forward,
 }
 
 

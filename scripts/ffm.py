@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Counterpart of the reference's scripts/ffm.py on synthetic ml-100k-shaped data: the reference's import
+lines, model construction, loss and optimizer (scripts/ffm.py), the same epoch loop through the Trainer mirror.
+
+    python scripts/ffm.py [--epochs 20] [--graph]
+"""
+import _common as c
+import torch.nn
+from torch import optim
+
+from model.ffm import FFM
+from trainer.trainer import Trainer
+
+a = c.args()
+device = c.device
+splits = c.feature_splits(a.train)
+model = FFM(43, 32).to(device)
+loss_fn = torch.nn.BCELoss()
+optimizer = optim.Adam(model.parameters(), lr=0.001, weight_decay=1e-5)
+trainer = Trainer(model, loss_fn, optimizer, graph=a.graph)
+c.run(trainer, splits, a.epochs)

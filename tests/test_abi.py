@@ -110,6 +110,10 @@ def _parse_header_prototypes():
                     kinds.append("head*")
                 elif "ctr_adam_tensor_t" in a:
                     kinds.append("adam*")
+                elif "ctr_rows_mark_t" in a:
+                    kinds.append("mark*")
+                elif "ctr_rows_table_t" in a:
+                    kinds.append("rows*")
                 elif a.startswith("float "):
                     kinds.append("f32")
                 elif a.startswith("double "):
@@ -149,12 +153,18 @@ def test_ctypes_signatures_match_header_prototypes(lib):
                 got.append("headgrad*")
             elif a is ctypes.POINTER(lib.AdamTensor):
                 got.append("adam*")
+            elif a is ctypes.POINTER(lib.RowsMark):
+                got.append("mark*")
+            elif a is ctypes.POINTER(lib.RowsTable):
+                got.append("rows*")
             elif a is ctypes.c_float:
                 got.append("f32")
             elif a is ctypes.c_double:
                 got.append("f64")
             elif a is ctypes.POINTER(ctypes.c_int32):
                 got.append("i32*")
+            elif a in (ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)):
+                got.append("ptr")  # host arrays of device pointers / of sizes (ctr_fields_*)
             else:
                 raise AssertionError(f"{name}: unexpected ctypes arg {a}")
         # a device `int32_t* err_flag` is passed as a raw pointer; only host int arrays are typed

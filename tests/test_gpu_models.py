@@ -433,3 +433,120 @@ def test_evaluator_matches_definitions():
     # the ranking AUC of the raw scores is the separately named extra.  9 (pos, neg) pairs;
     # pos > neg: (.9: 3) + (.4: 1) + (.6: 1 + tie .5) = 5.5
     assert abs(Evaluator.score_auc(y, p) - 5.5 / 9) < 1e-6
+
+
+def test_graphed_step_survives_pool_reallocation_between_replays():
+    """DESIGN "hipGraph" note (r1: a captured hipMemsetAsync of the BCE loss scalar faulted on replay).  The
+    buffers a captured step zeroes and writes -- the loss scalar, the flat gradient buffer, the reduction
+    workspaces -- live in the graph's private pool for the graph's lifetime.  This test replays a captured step,
+    then churns the allocator (big allocations, empty_cache, a SECOND captured step of another model whose
+    pool is carved afterwards), replays the first graph again and requires the same loss and gradients as an
+    eager step: the kernels that took over the zeroing write the same addresses a memset node would, so a
+    lifetime problem of those buffers would show here."""
+    from deeplearningrecommendationsystem_amd import synth
+    from deeplearningrecommendationsystem_amd.graph import GraphedStep
+    from deeplearningrecommendationsystem_amd.loss import BCELoss
+    from deeplearningrecommendationsystem_amd.model import NeuralCF, MatrixFactorization
+    torch.manual_seed(21)
+    gen = synth.generator(21)
+    u, i = synth.id_batch(8192, gen=gen)
+    y = synth.labels(8192, True, gen)
+    m = NeuralCF(943, 1682, 64, [128, 64, 32, 16, 8]).to(DEV)
+    ud, idv, yd = u.to(DEV), i.to(DEV), y.to(DEV)
+    # eager reference on the same weights
+    m.zero_grad(set_to_none=True)
+    loss_e = BCELoss()(m(ud, idv), yd)
+    loss_e.backward()
+    ref = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    loss_e = float(loss_e)
+    g1 = GraphedStep(m, BCELoss(), [ud, idv], yd)
+
+    def check():
+        loss = float(g1())
+        assert abs(loss - loss_e) <= 1e-6 * max(1.0, abs(loss_e))
+        for k, p in m.named_parameters():
+            floor = 1e-6 + 1e-5 * float(ref[k].abs().max())
+            torch.testing.assert_close(p.grad, ref[k], rtol=1e-4, atol=floor, msg=lambda s, k=k: f"{k}: {s}")
+
+    check()
+    check()
+    # churn: grow and release the ordinary pool, then capture another graph (its own private pool)
+    junk = [torch.zeros(64 << 20, device=DEV) for _ in range(4)]
+    del junk
+    torch.cuda.empty_cache()
+    m2 = MatrixFactorization(943, 1682, 64).to(DEV)
+    g2 = GraphedStep(m2, BCELoss(), [ud, idv], y.view(-1).to(DEV))
+    g2()
+    torch.cuda.empty_cache()
+    check()
+    g2()
+    check()
+
+
+# ---------------------------------------------------------------------------
+# N-id-field generalisation of DeepFM / PNN (BASELINE configs[2]: "26 fields x 1e6 vocab")
+# ---------------------------------------------------------------------------
+def _fields_case(batch, vocabs, seed, as_float=False):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.stack([torch.randint(0, v, (batch,), generator=g) for v in vocabs], 1)
+    ids[0, 0], ids[1 % batch, 0] = 0, vocabs[0] - 1           # first / last row
+    if batch > 4:
+        ids[2:4] = ids[4]                                      # duplicate samples -> accumulated gradient rows
+    y = (torch.rand(batch, 1, generator=g) < 0.5).float()
+    return [ids.float() if as_float else ids], y
+
+
+@pytest.mark.parametrize("fields,vocab,dim,hidden,batch,as_float", [
+    (26, 5000, 16, [64, 32, 1], 4096, False),      # configs[2] field count at test size
+    (3, [7, 50, 1000], 8, [16, 1], 333, False),    # a vocabulary per field, ragged batch
+    (6, 40, 32, [32, 16, 1], 1, False),            # single sample
+    (26, 300, 16, [32, 1], 2500, True),            # ids carried as float32 like the reference's id columns
+    (5, 64, 64, [16, 8, 1], 700, False),
+])
+def test_deepfm_n_fields_against_oracle(fields, vocab, dim, hidden, batch, as_float):
+    from deeplearningrecommendationsystem_amd.model import DeepFM
+    torch.manual_seed(fields * 10 + dim)
+    m = DeepFM(None, None, hidden, dim, num_fields=fields, vocab=vocab)
+    with torch.no_grad():
+        m.first_order_bias.fill_(0.3)
+    vocabs = [vocab] * fields if isinstance(vocab, int) else vocab
+    inputs, y = _fields_case(batch, vocabs, 31 + fields, as_float)
+    _vs_oracle("deepfm_fields", m, inputs, y)
+
+
+@pytest.mark.parametrize("fields,vocab,dim,hidden,batch", [
+    (26, 5000, 16, [64, 32], 4096),                # 325 inner products
+    (3, [7, 50, 1000], 8, [16, 8], 333),
+    (7, 100, 16, [32, 16], 1),
+])
+def test_pnn_n_fields_against_oracle(fields, vocab, dim, hidden, batch):
+    from deeplearningrecommendationsystem_amd.model import PNN
+    torch.manual_seed(fields * 10 + dim + 1)
+    m = PNN(dim, hidden, num_fields=fields, vocab=vocab)
+    vocabs = [vocab] * fields if isinstance(vocab, int) else vocab
+    inputs, y = _fields_case(batch, vocabs, 41 + fields)
+    _vs_oracle("pnn_fields", m, inputs, y)
+
+
+def test_n_field_ctor_defaults_leave_the_reference_models_unchanged():
+    from deeplearningrecommendationsystem_amd.model import DeepFM, PNN
+    assert "user_embedding.weight" in DeepFM(943, 1682, [32, 1], 8).state_dict()
+    assert "user_embed.weight" in PNN(8, [16, 8]).state_dict()
+    with pytest.raises(ValueError):
+        DeepFM(None, None, [32, 1], 8, num_fields=26)           # vocab missing
+    with pytest.raises(ValueError):
+        PNN(8, [16, 8], "out", num_fields=4, vocab=10)           # inner mode only
+
+
+@pytest.mark.parametrize("script", ["mf", "neuralcf", "ffm", "pnn", "deepcrossing", "deepfm", "din", "dien"])
+def test_script_counterparts_run_with_the_reference_import_lines(script, capsys, monkeypatch):
+    """scripts/<m>.py: the reference's ``from model.<m> import ...`` / ``from trainer.trainer import Trainer``
+    lines resolved through compat/, the script's model construction, two epochs on synthetic data"""
+    import runpy
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.setattr(sys, "argv", [script + ".py", "--epochs", "2", "--train", "6000"])
+    monkeypatch.syspath_prepend(os.path.join(root, "scripts"))
+    runpy.run_path(os.path.join(root, "scripts", script + ".py"), run_name="__main__")
+    out = capsys.readouterr().out
+    assert "Epoch 2:" in out and "Training Loss" in out and "ROC AUC Score" in out

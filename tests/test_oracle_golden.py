@@ -79,3 +79,71 @@ def test_bce_clamps_log_at_minus_100():
     p = torch.tensor([0.0, 1.0, 0.5])
     y = torch.tensor([1.0, 0.0, 1.0])
     assert torch.equal(orc.bce_loss(p, y), torch.nn.BCELoss()(p, y))
+
+
+# ---------------------------------------------------------------------------
+# N-field generalisation (BASELINE configs[2]): the reference cannot build such a model, so the F-field
+# restatements are pinned THROUGH the pinned six-field oracle: with the four bag tables (and the dense part of
+# the wide Linear) zeroed, the reference model IS a two-id-field model padded with four zero vectors, and the
+# F = 6 field restatement with one-row zero tables in fields 2..5 must reproduce it -- outputs, loss and the
+# gradients of every shared parameter -- on the reference fixture's own parameters and inputs.
+# ---------------------------------------------------------------------------
+def _zero_bags(params, names):
+    p = {k: v.clone() for k, v in params.items()}
+    for n in names:
+        p[n + ".weight"].zero_()
+    return p
+
+
+@pytest.mark.parametrize("name", ["deepfm_s0", "deepfm_b37"])
+def test_deepfm_fields_oracle_reduces_to_the_pinned_six_field_oracle(name):
+    g = gu.load(name)
+    x, y = g["inputs"][0], g["y"]
+    bags = ["age_embedding", "gender_embedding", "occupation_embedding", "movie_embedding"]
+    p6 = _zero_bags(g["params"], bags + ["wide"])          # wide.weight zeroed, wide.bias kept
+    prob6, loss6, grads6 = orc.step("deepfm", p6, [x], y)
+    dim = p6["user_embedding.weight"].shape[1]
+    pf = {"embeddings.0.weight": p6["user_embedding.weight"], "embeddings.1.weight": p6["item_embedding.weight"],
+          "first_order.0.weight": p6["user.weight"], "first_order.1.weight": p6["item.weight"],
+          "first_order_bias": p6["wide.bias"]}
+    for f in range(2, 6):
+        pf[f"embeddings.{f}.weight"] = torch.zeros(1, dim)
+        pf[f"first_order.{f}.weight"] = torch.zeros(1, 1)
+    for k, v in p6.items():
+        if k.startswith(("linear.", "dnn_network.", "output.")):
+            pf[k] = v
+    ids = torch.cat([x[:, :2].long(), torch.zeros(x.shape[0], 4, dtype=torch.int64)], 1)
+    probf, lossf, gradsf = orc.step("deepfm_fields", pf, [ids], y)
+    torch.testing.assert_close(probf, prob6, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(lossf, loss6, rtol=1e-6, atol=1e-7)
+    same = {"embeddings.0.weight": "user_embedding.weight", "embeddings.1.weight": "item_embedding.weight",
+            "first_order.0.weight": "user.weight", "first_order.1.weight": "item.weight", "first_order_bias": "wide.bias"}
+    same.update({k: k for k in pf if k.startswith(("linear.", "dnn_network.", "output."))})
+    for kf, k6 in same.items():
+        torch.testing.assert_close(gradsf[kf], grads6[k6], rtol=1e-5, atol=1e-7, msg=lambda m, kf=kf: f"{kf}: {m}")
+    # ids carried as floats (the reference's own convention for its two id columns) give the same result
+    probx, _, _ = orc.step("deepfm_fields", pf, [ids.float()], y)
+    assert torch.equal(probx, probf)
+
+
+@pytest.mark.parametrize("name", ["pnn_s0", "pnn_b37"])
+def test_pnn_fields_oracle_reduces_to_the_pinned_six_field_oracle(name):
+    g = gu.load(name)
+    x, y = g["inputs"][0], g["y"]
+    p6 = _zero_bags(g["params"], ["age_embed", "gender_embed", "occupation_embed", "movie_embed"])
+    prob6, loss6, grads6 = orc.step("pnn", p6, [x], y)
+    dim = p6["user_embed.weight"].shape[1]
+    pf = {"embeddings.0.weight": p6["user_embed.weight"], "embeddings.1.weight": p6["item_embed.weight"]}
+    for f in range(2, 6):
+        pf[f"embeddings.{f}.weight"] = torch.zeros(1, dim)
+    for k, v in p6.items():
+        if k.startswith(("product.", "dnn.", "output.")):
+            pf[k] = v
+    ids = torch.cat([x[:, :2].long(), torch.zeros(x.shape[0], 4, dtype=torch.int64)], 1)
+    probf, lossf, gradsf = orc.step("pnn_fields", pf, [ids], y)
+    torch.testing.assert_close(probf, prob6, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(lossf, loss6, rtol=1e-6, atol=1e-7)
+    same = {"embeddings.0.weight": "user_embed.weight", "embeddings.1.weight": "item_embed.weight"}
+    same.update({k: k for k in pf if k.startswith(("product.", "dnn.", "output."))})
+    for kf, k6 in same.items():
+        torch.testing.assert_close(gradsf[kf], grads6[k6], rtol=1e-5, atol=1e-7, msg=lambda m, kf=kf: f"{kf}: {m}")
