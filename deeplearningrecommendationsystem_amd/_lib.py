@@ -15,8 +15,8 @@ import torch  # noqa: F401  (maps libamdhip64 first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTRHIP_LIB", os.path.join(_HERE, "libctrhip.so"))  # env override: A/B builds
-ABI_VERSION = 14
-DIN_TRIPLE, DIN_PAIR = 0, 1  # layouts of the DIN attention operand (include/ctrhip.h)
+ABI_VERSION = 15
+DIN_TRIPLE, DIN_PAIR, DIN_H = 0, 1, 2  # layouts of the DIN attention operand (include/ctrhip.h)
 
 CTR_MAX_FIELDS = 32
 FIELD_ID_I64, FIELD_ID_F32, FIELD_BAG, FIELD_DENSE, FIELD_PROD_I64 = range(5)
@@ -122,6 +122,9 @@ SIGNATURES = {
     "ctr_fold_head_bwd": (_i, [_p, _i, _p, _l, _p, _i, _i, _p, _p, _p, _p, _l, _p, _p, _p]),
     "ctr_bce_fwd": (_i, [_p, _l, _p, _l, _l, _p, _p, _l, _p, _p, _p]),
     "ctr_bce_bwd": (_i, [_p, _l, _p, _l, _l, _p, _p, _l, _p]),
+    "ctr_din_scatter_bwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _p, _p, _l, _i, _p, _p]),
+    "ctr_linear_group_fwd": (_i, [_p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _l, _i, _i, _i, _p]),
+    "ctr_linear_dx_masked": (_i, [_p, _l, _p, _l, _p, _l, _i, _p, _l, _i, _p, _l, _p, _l, _i, _l, _i, _i, _p]),
     "ctr_rows_mark": (_i, [C.POINTER(RowsMark), _i, _p]),
     "ctr_adam_rows": (_i, [C.POINTER(RowsTable), _i, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _l, _p]),
     "ctr_rows_discard": (_i, [C.POINTER(RowsTable), _i, _p]),

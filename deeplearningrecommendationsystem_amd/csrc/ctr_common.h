@@ -133,6 +133,9 @@ int ctr_skinny_dw(const float* x, int64_t ldx, const float* y, int64_t ldy, cons
 bool ctr_gemm_dlds_ok(const float* x, int64_t ldx, const float* w, int64_t ldw, int64_t m, int n, int k);
 int ctr_gemm_dlds_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* res,
                       int64_t ldr, float* y, int64_t ldy, int64_t m, int n, int k, int act, hipStream_t st);
+int ctr_gemm_dlds_fwd_group(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* res,
+                            int64_t ldr, int group, float* y, int64_t ldy, int64_t m, int n, int k, int act,
+                            hipStream_t st);
 // gemm_dlds_dw.hip: weight gradient with direct global->LDS operand loads
 bool ctr_gemm_dlds_dw_ok(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
                          const float* gw, int64_t ldgw, int64_t m, int n, int k, int act);

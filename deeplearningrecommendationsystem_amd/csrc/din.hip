@@ -74,7 +74,7 @@ template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 concat_fwd_kernel(const SeqGeom g, const float* __restrict__ table, int64_t vocab, const int64_t* __restrict__ hist,
                   const int64_t* __restrict__ target, float* __restrict__ c, int64_t ldc, float* __restrict__ tvec,
-                  int64_t ldt, int32_t* err, int pair) {
+                  int64_t ldt, int32_t* err, int layout) {
   const int sub = threadIdx.x % g.lpr;
   const int64_t rows = g.batch * g.len;
   const int64_t groups = ((int64_t)gridDim.x * blockDim.x) / g.lpr;
@@ -91,12 +91,12 @@ concat_fwd_kernel(const SeqGeom g, const float* __restrict__ table, int64_t voca
       for (int v = 0; v < VEC; ++v) d.v[v] = h.v[v] - t.v[v];
       float* dst = c + row * ldc + e;
       h.store(dst);
-      if (pair) {
+      if (layout == CTR_DIN_PAIR) {
         t.store(dst + g.dim);
-      } else {
+      } else if (layout == CTR_DIN_TRIPLE) {
         d.store(dst + g.dim);
         t.store(dst + 2 * g.dim);
-      }
+      }  // CTR_DIN_H: the gathered rows only
       if (l == 0 && tvec) t.store(tvec + b * ldt + e);
     }
   }
@@ -372,6 +372,57 @@ concat_bwd_kernel(const SeqGeom g, const int64_t* __restrict__ hist, const int64
   }
 }
 
+// Scatter of the history positions' gradient rows for the E-wide attention operand (CTR_DIN_H):
+//   gtable[hist[b,l], e] += gh[(b,l), e] + attn[b,l] * gpool[b or (b,l), e]
+// Flat (position, element) mapping, one dword per lane: the lanes of a wave cover whole 4*E-byte runs of ONE
+// gradient row per atomic instruction (256 B at E = 64, the shape that runs at the memory-side atomic rate),
+// UNROLL positions in flight per lane -- the wave-per-sample loop of concat_bwd_kernel is one dependent
+// id -> row round trip per position (1.17 ms at cfg5 against a ~0.5 ms atomic floor).  Row 0 (the padding id, a
+// quarter of all positions) is summed per workgroup in LDS.
+template <int UNROLL>
+__global__ void __launch_bounds__(kBlock)
+seq_scatter_kernel(const int64_t* __restrict__ hist, int64_t vocab, uint32_t rows, int eshift, const CtrFastDiv div_len,
+                   const float* __restrict__ gh, int64_t ldgh, const float* __restrict__ attn,
+                   const float* __restrict__ gpool, int64_t ldgp, int summed, float* __restrict__ gtable) {
+  extern __shared__ float s_pad[];
+  const uint32_t dim = 1u << eshift;
+  for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x) s_pad[i] = 0.0f;
+  __syncthreads();
+  const uint32_t rpb = kBlock >> eshift;          // positions per workgroup pass and unroll slot
+  const uint32_t e = threadIdx.x & (dim - 1), slot = threadIdx.x >> eshift;
+  bool any0 = false;
+  for (uint32_t base = blockIdx.x * rpb * UNROLL; base < rows; base += gridDim.x * rpb * UNROLL) {
+    int64_t r[UNROLL];
+    float v[UNROLL];
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k) {
+      const uint32_t row = base + slot + k * rpb;
+      r[k] = -1;
+      v[k] = 0.0f;
+      if (row < rows) {
+        r[k] = ctr_ldg(hist + row);
+        const uint32_t b = ctr_div(row, div_len);
+        const float go = ctr_ldg(gpool + (summed ? (int64_t)b : (int64_t)row) * ldgp + e);
+        v[k] = fmaf(ctr_ldg(attn + row), go, ctr_ldg(gh + (int64_t)row * ldgh + e));
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < UNROLL; ++k) {
+      if (r[k] > 0 && r[k] < vocab) ctr_atomic_add_global(gtable + (r[k] << eshift) + e, v[k]);
+      else if (r[k] == 0) {
+        atomicAdd(s_pad + e, v[k]);
+        any0 = true;
+      }
+    }
+  }
+  if (__syncthreads_or(any0)) {
+    for (uint32_t i = threadIdx.x; i < dim; i += blockDim.x) {
+      const float t = s_pad[i];
+      if (t != 0.0f) ctr_atomic_add_global(gtable + i, t);
+    }
+  }
+}
+
 inline int wave_grid(int64_t batch) {
   int64_t blocks = ctr_ceil_div(batch, kBlock / 64);
   return (int)(blocks < 2048 ? (blocks < 1 ? 1 : blocks) : 2048);
@@ -389,9 +440,9 @@ extern "C" int ctr_din_concat_fwd(const float* table, int64_t vocab, int dim, co
                                   int64_t ldt, int layout, int32_t* err_flag, void* stream) {
   CTR_REQUIRE(batch >= 0 && len >= 0, CTR_EINVAL);
   if (batch == 0 || len == 0) return CTR_OK;
-  CTR_REQUIRE(layout == CTR_DIN_TRIPLE || layout == CTR_DIN_PAIR, CTR_EINVAL);
-  const int pair = layout == CTR_DIN_PAIR;
-  CTR_REQUIRE(table && hist && target && c && vocab > 0 && dim > 0 && ldc >= (pair ? 2 : 3) * (int64_t)dim, CTR_EINVAL);
+  CTR_REQUIRE(layout == CTR_DIN_TRIPLE || layout == CTR_DIN_PAIR || layout == CTR_DIN_H, CTR_EINVAL);
+  const int width = layout == CTR_DIN_TRIPLE ? 3 : (layout == CTR_DIN_PAIR ? 2 : 1);
+  CTR_REQUIRE(table && hist && target && c && vocab > 0 && dim > 0 && ldc >= width * (int64_t)dim, CTR_EINVAL);
   CTR_REQUIRE(!tvec || ldt >= dim, CTR_EINVAL);
   const bool al = ctr_aligned16(table) && ctr_aligned16(c) && ldc % 4 == 0 && (!tvec || (ctr_aligned16(tvec) && ldt % 4 == 0));
   const SeqGeom g = make_geom(batch, len, dim, al);
@@ -399,10 +450,10 @@ extern "C" int ctr_din_concat_fwd(const float* table, int64_t vocab, int dim, co
   hipStream_t st = (hipStream_t)stream;
   if (g.vec == 4)
     hipLaunchKernelGGL(concat_fwd_kernel<4>, dim3(grid), dim3(kBlock), 0, st, g, table, vocab, hist, target, c, ldc,
-                       tvec, ldt, err_flag, pair);
+                       tvec, ldt, err_flag, layout);
   else
     hipLaunchKernelGGL(concat_fwd_kernel<1>, dim3(grid), dim3(kBlock), 0, st, g, table, vocab, hist, target, c, ldc,
-                       tvec, ldt, err_flag, pair);
+                       tvec, ldt, err_flag, layout);
   return ctr_launch_status();
 }
 
@@ -468,5 +519,24 @@ extern "C" int ctr_din_concat_bwd(const int64_t* hist, const int64_t* target, in
   else
     hipLaunchKernelGGL(concat_bwd_kernel<1>, dim3(grid), dim3(kBlock), dyn, st, g, hist, target, vocab, gc, ldc, attn,
                        gout, ldgo, summed, gt_extra, ldgt, gtable, pair);
+  return ctr_launch_status();
+}
+
+extern "C" int ctr_din_scatter_bwd(const int64_t* hist, int64_t vocab, int64_t batch, int len, int dim, const float* gh,
+                                   int64_t ldgh, const float* attn, const float* gpool, int64_t ldgp, int summed,
+                                   float* gtable, void* stream) {
+  CTR_REQUIRE(batch >= 0 && len >= 0, CTR_EINVAL);
+  if (batch == 0 || len == 0) return CTR_OK;
+  CTR_REQUIRE(hist && gh && attn && gpool && gtable && vocab > 0 && ldgh >= dim && ldgp >= dim, CTR_EINVAL);
+  CTR_REQUIRE(dim >= 1 && dim <= 256 && (dim & (dim - 1)) == 0 && batch * len < (1ll << 32), CTR_ELIMIT);
+  int eshift = 0;
+  while ((1 << eshift) < dim) ++eshift;
+  const uint32_t rows = (uint32_t)(batch * len);
+  constexpr int kUnroll = 4;
+  int64_t grid = ctr_ceil_div((int64_t)rows, (kBlock / dim) * kUnroll);
+  if (grid > 256 * 8) grid = 256 * 8;
+  hipLaunchKernelGGL(seq_scatter_kernel<kUnroll>, dim3((unsigned)grid), dim3(kBlock), (size_t)dim * sizeof(float),
+                     (hipStream_t)stream, hist, vocab, rows, eshift, ctr_fastdiv((uint32_t)len), gh, ldgh, attn, gpool, ldgp,
+                     summed, gtable);
   return ctr_launch_status();
 }

@@ -33,6 +33,8 @@ struct DldsArgs {
   const float* res; int64_t ldr;
   float* y; int64_t ldy;
   int64_t m; int n; int64_t k; int act;
+  int res_group;        // > 1: residual row of output row i is i / res_group (one row per group of consecutive rows)
+  CtrFastDiv res_div;
 };
 
 // s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
@@ -211,13 +213,27 @@ gemm_fwd_dlds_kernel(const DldsArgs a) {
 #pragma unroll
           for (int c = 1; c < CH; ++c) v[e] += acc[n][c][e];
         }
-        if (a.res) {
+        if (a.res && a.res_group >= 32) {
+          // grouped residual (DIN: u[b] for the L rows of sample b): the wave's 32 rows lie in at most two groups,
+          // so a lane needs two values of its column -- 2 loads instead of 16 (882 -> us on 3276800 x 128 x 64)
+          const int64_t first = i0 + 32 * wave;
+          const int64_t g0 = (int64_t)ctr_div((uint32_t)(first < a.m ? first : a.m - 1), a.res_div);
+          const int64_t edge = (g0 + 1) * a.res_group;
+          const float r0 = ctr_ldg(a.res + g0 * a.ldr + j);
+          const float r1 = ctr_ldg(a.res + (edge < a.m ? g0 + 1 : g0) * a.ldr + j);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int64_t i = first + (e & 3) + 8 * (e >> 2) + 4 * h;
+            v[e] += i < edge ? r0 : r1;
+          }
+        } else if (a.res) {
           // all 16 residual values in flight at once (the wait for them also drains the ring's loads)
           float rv[16];
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int64_t i = i0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h;
-            rv[e] = i < a.m ? ctr_ldg(a.res + i * a.ldr + j) : 0.0f;
+            const int64_t ri = a.res_group > 1 ? (int64_t)ctr_div((uint32_t)(i < a.m ? i : 0), a.res_div) : i;
+            rv[e] = i < a.m ? ctr_ldg(a.res + ri * a.ldr + j) : 0.0f;
           }
 #pragma unroll
           for (int e = 0; e < 16; ++e) v[e] += rv[e];
@@ -239,7 +255,8 @@ bool ctr_gemm_dlds_ok(const float* x, int64_t ldx, const float* w, int64_t ldw, 
 }
 
 static int launch_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* res,
-                      int64_t ldr, float* y, int64_t ldy, int64_t m, int n, int k, int act, hipStream_t st) {
+                      int64_t ldr, float* y, int64_t ldy, int64_t m, int n, int k, int act, hipStream_t st,
+                      int res_group = 1) {
   const int nt = n <= 32 ? 1 : (n <= 64 ? 2 : 4);
   const int64_t mtiles = ctr_ceil_div(m, kBM);
   const int64_t ny = ctr_ceil_div(n, 32 * nt);
@@ -247,12 +264,21 @@ static int launch_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, 
   if (gx > mtiles) gx = mtiles;
   if (gx < 1) gx = 1;
   CTR_REQUIRE(ny <= 65535, CTR_ELIMIT);
-  const DldsArgs a{x, ldx, w, ldw, bias, res, ldr, y, ldy, m, n, (int64_t)k, act};
+  CTR_REQUIRE(res_group >= 1 && (res_group == 1 || m < (1ll << 32)), CTR_ELIMIT);
+  const DldsArgs a{x, ldx, w, ldw, bias, res, ldr, y, ldy, m, n, (int64_t)k, act, res_group,
+                   ctr_fastdiv((uint32_t)res_group)};
   const dim3 grid((unsigned)gx, (unsigned)ny);
   if (nt == 1) hipLaunchKernelGGL(gemm_fwd_dlds_kernel<1>, grid, dim3(kThreads), 0, st, a);
   else if (nt == 2) hipLaunchKernelGGL(gemm_fwd_dlds_kernel<2>, grid, dim3(kThreads), 0, st, a);
   else hipLaunchKernelGGL(gemm_fwd_dlds_kernel<4>, grid, dim3(kThreads), 0, st, a);
   return ctr_launch_status();
+}
+
+// Y = act(X W^T + b + R[row / group]): one residual row per `group` consecutive output rows
+int ctr_gemm_dlds_fwd_group(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* res,
+                            int64_t ldr, int group, float* y, int64_t ldy, int64_t m, int n, int k, int act,
+                            hipStream_t st) {
+  return launch_fwd(x, ldx, w, ldw, bias, res, ldr, y, ldy, m, n, k, act, st, group);
 }
 
 int ctr_gemm_dlds_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* res,
@@ -270,4 +296,16 @@ int ctr_gemm_dlds_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, 
                       ldr, y + main_n, ldy, m, rem, k, act, st);
   }
   return launch_fwd(x, ldx, w, ldw, bias, res, ldr, y, ldy, m, n, k, act, st);
+}
+
+// C ABI (include/ctrhip.h): Y = act(X W^T + b + R[row / group])
+extern "C" int ctr_linear_group_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
+                                    const float* res, int64_t ldr, int group, float* y, int64_t ldy, int64_t m, int n,
+                                    int k, int act, void* stream) {
+  CTR_REQUIRE(m >= 0 && n >= 1 && k >= 1, CTR_EINVAL);
+  if (m == 0) return CTR_OK;
+  CTR_REQUIRE(x && w && res && y && group >= 1 && ldx >= k && ldw >= k && ldy >= n && ldr >= n, CTR_EINVAL);
+  CTR_REQUIRE(act >= CTR_ACT_NONE && act <= CTR_ACT_SIGMOID, CTR_EINVAL);
+  CTR_REQUIRE(ctr_gemm_dlds_ok(x, ldx, w, ldw, m, n, k) && n <= 128, CTR_ELIMIT);  // one launch: no column split
+  return ctr_gemm_dlds_fwd_group(x, ldx, w, ldw, bias, res, ldr, group, y, ldy, m, n, k, act, (hipStream_t)stream);
 }

@@ -28,6 +28,11 @@ struct DxArgs {
   const float* w; int64_t ldw;
   float* gx; int64_t ldgx;
   int64_t m; int n; int k; int accumulate;
+  // optional epilogue (EPI instantiations; DIN attention, see ctr_linear_dx_masked): gx *= act'(xin) -- the layer's
+  // own input is the previous layer's activation output -- and per-group column sums of the masked gx added to
+  // gsum[row / group]
+  const float* xin; int64_t ldxin; int act_in;
+  float* gsum; int64_t ldgsum; int group;
 };
 
 template <int N>
@@ -89,7 +94,7 @@ __device__ __forceinline__ void fetch_w(float* stage, const float* __restrict__ 
   }
 }
 
-template <int NT, int ACT>
+template <int NT, int ACT, bool EPI = false>
 __global__ void __launch_bounds__(kThreads, 2)
 gemm_dx_dlds_kernel(const DxArgs a) {
   constexpr int BW = 32 * NT;
@@ -190,6 +195,65 @@ gemm_dx_dlds_kernel(const DxArgs a) {
       stage = stage + 1 == kStages ? 0 : stage + 1;
     }
     // C/D map: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if constexpr (EPI) {
+      // mask by act'(xin) and per-group column sums.  The mask values of TWO column tiles are requested before
+      // the first is used: every wait on an epilogue load also drains the ring's loads of the next tile, so one
+      // dependent group of 16 loads per column tile stalled the pipeline four times per row tile (+500 us on
+      // DIN's 3276800 x 64 x 128 layer).
+      constexpr int NB = NT >= 2 ? 2 : 1;
+      const int64_t first = i0 + 32 * wave;
+      const int64_t g0 = a.gsum ? first / a.group : 0;
+      const int64_t edge = (g0 + 1) * (int64_t)a.group;  // first row of the next group
+#pragma unroll
+      for (int nb0 = 0; nb0 < NT; nb0 += NB) {
+        float xv[NB][16];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          const int col = c0 + 32 * (nb0 + q) + r;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int64_t i = first + (e & 3) + 8 * (e >> 2) + 4 * h;
+            xv[q][e] = (a.xin && i < a.m && col < a.k) ? ctr_ldg(a.xin + i * a.ldxin + col) : 1.0f;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          const int nb = nb0 + q;
+          const int col = c0 + 32 * nb + r;
+          if (col < a.k) {
+            float v[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              v[e] = acc[nb][0][e];
+#pragma unroll
+              for (int c = 1; c < CH; ++c) v[e] += acc[nb][c][e];
+              if (a.xin) v[e] *= ctr_act_grad(xv[q][e], a.act_in);
+            }
+            float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int64_t i = first + (e & 3) + 8 * (e >> 2) + 4 * h;
+              if (i < a.m) {
+                ctr_stg(a.gx + i * a.ldgx + col, v[e]);
+                if (i < edge) s0 += v[e];
+                else s1 += v[e];
+              }
+            }
+            if (a.gsum) {
+              // the wave's 32 rows lie in at most two groups (group >= 32, checked on the host): fold the two
+              // half-waves, one atomic per column and side
+              s0 += __shfl_xor(s0, 32, 64);
+              s1 += __shfl_xor(s1, 32, 64);
+              if (h == 0 && first < a.m) {
+                ctr_atomic_add_global(a.gsum + g0 * a.ldgsum + col, s0);
+                if (edge < first + 32 && edge < a.m) ctr_atomic_add_global(a.gsum + (g0 + 1) * a.ldgsum + col, s1);
+              }
+            }
+          }
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int nb = 0; nb < NT; ++nb) {
       const int col = c0 + 32 * nb + r;
@@ -230,8 +294,15 @@ bool ctr_gemm_dlds_dx_ok(const float* w, int64_t ldw, const float* y, int64_t ld
   return act == CTR_ACT_NONE || y != nullptr;
 }
 
+struct DxEpilogue {
+  bool on = false;
+  const float* xin = nullptr; int64_t ldxin = 0; int act_in = CTR_ACT_NONE;
+  float* gsum = nullptr; int64_t ldgsum = 0; int group = 1;
+};
+
 static int launch_dx(const float* w, int64_t ldw, const float* y, int64_t ldy, const float* gy, int64_t ldgy, float* gx,
-                     int64_t ldgx, int accumulate, int64_t m, int n, int k, int act, hipStream_t st) {
+                     int64_t ldgx, int accumulate, int64_t m, int n, int k, int act, hipStream_t st,
+                     const DxEpilogue& ep = DxEpilogue()) {
   const int nt = k <= 32 ? 1 : (k <= 64 ? 2 : 4);
   const int64_t mtiles = ctr_ceil_div(m, kBM);
   const int64_t ny = ctr_ceil_div(k, 32 * nt);
@@ -239,9 +310,14 @@ static int launch_dx(const float* w, int64_t ldw, const float* y, int64_t ldy, c
   if (gx_ > mtiles) gx_ = mtiles;
   if (gx_ < 1) gx_ = 1;
   CTR_REQUIRE(ny <= 65535, CTR_ELIMIT);
-  const DxArgs a{gy, ldgy, act == CTR_ACT_NONE ? nullptr : y, ldy, w, ldw, gx, ldgx, m, n, k, accumulate};
+  const DxArgs a{gy, ldgy, act == CTR_ACT_NONE ? nullptr : y, ldy, w, ldw, gx, ldgx, m, n, k, accumulate,
+                 ep.xin, ep.ldxin, ep.act_in, ep.gsum, ep.ldgsum, ep.group};
   const dim3 grid((unsigned)gx_, (unsigned)ny);
-#define CTR_DX(NT_, ACT_) hipLaunchKernelGGL((gemm_dx_dlds_kernel<NT_, ACT_>), grid, dim3(kThreads), 0, st, a)
+#define CTR_DX(NT_, ACT_)                                                                                  \
+  do {                                                                                                     \
+    if (ep.on) hipLaunchKernelGGL((gemm_dx_dlds_kernel<NT_, ACT_, true>), grid, dim3(kThreads), 0, st, a); \
+    else hipLaunchKernelGGL((gemm_dx_dlds_kernel<NT_, ACT_>), grid, dim3(kThreads), 0, st, a);             \
+  } while (0)
 #define CTR_DX_ACT(NT_)                                      \
   do {                                                       \
     if (act == CTR_ACT_NONE) CTR_DX(NT_, CTR_ACT_NONE);      \
@@ -269,4 +345,28 @@ int ctr_gemm_dlds_dx(const float* w, int64_t ldw, const float* y, int64_t ldy, c
     return launch_dx(w + main_k, ldw, y, ldy, gy, ldgy, gx + main_k, ldgx, accumulate, m, n, rem, act, st);
   }
   return launch_dx(w, ldw, y, ldy, gy, ldgy, gx, ldgx, accumulate, m, n, k, act, st);
+}
+
+// C ABI (include/ctrhip.h): gX = ((gY * act'(Y)) W) * act_in'(Xin);  gsum[row / group, :] += gX[row, :]
+extern "C" int ctr_linear_dx_masked(const float* w, int64_t ldw, const float* y, int64_t ldy, const float* gy,
+                                    int64_t ldgy, int act, const float* xin, int64_t ldxin, int act_in, float* gx,
+                                    int64_t ldgx, float* gsum, int64_t ldgsum, int group, int64_t m, int n, int k,
+                                    void* stream) {
+  CTR_REQUIRE(m >= 0 && n >= 1 && k >= 1, CTR_EINVAL);
+  if (m == 0) return CTR_OK;
+  CTR_REQUIRE(w && gy && gx && ldw >= k && ldgy >= n && ldgx >= k, CTR_EINVAL);
+  CTR_REQUIRE(act >= CTR_ACT_NONE && act <= CTR_ACT_SIGMOID && act_in >= CTR_ACT_NONE && act_in <= CTR_ACT_SIGMOID, CTR_EINVAL);
+  CTR_REQUIRE(act == CTR_ACT_NONE || (y && ldy >= n), CTR_EINVAL);
+  CTR_REQUIRE(act_in == CTR_ACT_NONE || (xin && ldxin >= k), CTR_EINVAL);
+  CTR_REQUIRE(!gsum || (group >= 32 && ldgsum >= k), CTR_EINVAL);  // a wave's 32 rows span at most two groups
+  CTR_REQUIRE(ctr_gemm_dlds_dx_ok(w, ldw, y, ldy, gy, ldgy, m, n, k, act) && k <= 128, CTR_ELIMIT);
+  DxEpilogue ep;
+  ep.on = true;
+  ep.xin = act_in == CTR_ACT_NONE ? nullptr : xin;
+  ep.ldxin = ldxin;
+  ep.act_in = act_in;
+  ep.gsum = gsum;
+  ep.ldgsum = ldgsum;
+  ep.group = gsum ? group : 1;
+  return launch_dx(w, ldw, y, ldy, gy, ldgy, gx, ldgx, 0, m, n, k, act, (hipStream_t)stream, ep);
 }

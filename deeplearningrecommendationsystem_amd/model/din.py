@@ -35,6 +35,11 @@ def unfold_attention_grad(gfolded, gw1, dim):
     gw1[:, 2 * dim:].copy_(g2)
 
 
+def _lib_field_id():
+    from .._lib import FIELD_ID_I64
+    return FIELD_ID_I64
+
+
 def fc_layers(p):
     return [Layer(p[0], p[1], ACT_RELU), Layer(p[2], p[3], ACT_RELU), Layer(p[4], p[5], ACT_SIGMOID)]
 
@@ -135,9 +140,85 @@ class DIN(SequenceModel):
             params[0] = rows
         return self._run_sequence(hist, target_item, params)
 
+    # ---- attention on the E-wide operand: W1 [h, h-t, t] + b1 = (Wa+Wb) h + u[b],  u[b] = (Wc-Wb) t_b + b1
+    # (model/din.py:39-44).  The GEMM over all B*L positions contracts E columns instead of 3E (reference) or 2E
+    # (the [h, t] operand below); the per-sample term rides in the GEMM epilogue, its gradient comes out of the
+    # layer-2 input-gradient epilogue as per-sample column sums.
+    e_wide = True
+
+    def _use_e_wide(self, hist, dim):
+        n1 = self.attention[0].weight.shape[0]
+        return (self.e_wide and dim >= 4 and dim <= 256 and (dim & (dim - 1)) == 0 and hist.shape[1] >= 32 and n1 <= 128
+                and self.attention[2].weight.shape[0] >= 4 and hist.numel() < 2 ** 32)
+
+    def _forward_e_wide(self, hist, target, params):
+        table = params[0]
+        att, fc = attention_layers(params[1:7]), fc_layers(params[7:13])
+        batch, length = hist.shape
+        dim, dev = table.shape[1], table.device
+        w1 = att[0].weight
+        wf = torch.empty((2, w1.shape[0], dim), dtype=torch.float32, device=dev)
+        torch.add(w1[:, :dim], w1[:, dim:2 * dim], out=wf[0])        # Wh = Wa + Wb
+        torch.sub(w1[:, 2 * dim:], w1[:, dim:2 * dim], out=wf[1])    # Wu = Wc - Wb
+        hrows = torch.empty((batch * length, dim), dtype=torch.float32, device=dev)
+        fcin = torch.empty((batch, 2 * dim), dtype=torch.float32, device=dev)
+        ops.din_concat_fwd(table, hist, target, hrows, fcin[:, dim:], self._flag, h_only=True)
+        u = ops.linear_fwd(fcin[:, dim:], wf[1], att[0].bias)                       # (B, n1)
+        z1 = ops.linear_group_fwd(hrows, wf[0], None, u, length, ACT_RELU)          # (B*L, n1)
+        h2 = ops.linear_fwd(z1, att[1].weight, att[1].bias, ACT_RELU)
+        score = ops.linear_fwd(h2, att[2].weight, att[2].bias, ACT_NONE)
+        attn = torch.empty((batch, length), dtype=torch.float32, device=dev)
+        ops.din_pool_fwd(score, hrows, batch, length, dim, attn, fcin[:, :dim], summed=True)
+        fc_acts = ops.mlp_fwd(fcin, fc)
+        return fc_acts[-1], ("e", hrows, z1, h2, attn, fc_acts, wf)
+
+    def _backward_e_wide(self, state, hist, target, params, gprob):
+        _, hrows, z1, h2, attn, fc_acts, wf = state
+        table = params[0]
+        att, fc = attention_layers(params[1:7]), fc_layers(params[7:13])
+        w1, b1 = att[0].weight, att[0].bias
+        batch, length = hist.shape
+        dim, dev = table.shape[1], table.device
+        n1 = w1.shape[0]
+        fcin = fc_acts[0]
+        zeros = _zero_grads(self, params)
+        fc_grads, gfcin = ops.mlp_bwd(fc_acts, fc, gprob, None, zeros=zeros)
+        gscore = torch.empty((batch * length, 1), dtype=torch.float32, device=dev)
+        ops.din_pool_bwd(attn, hrows, batch, length, dim, gfcin[:, :dim], True, gscore)
+        # layer 3 (n2 -> 1), layer 2 (n1 -> n2, ReLU)
+        gh2 = torch.empty_like(h2)
+        ops.linear_bwd(h2, att[2].weight, None, gscore, ACT_NONE, gh2, zeros[id(att[2].weight)], zeros[id(att[2].bias)])
+        ops.linear_bwd(z1, att[1].weight, h2, gh2, ACT_RELU, None, zeros[id(att[1].weight)], zeros[id(att[1].bias)])
+        gz1 = torch.empty_like(z1)
+        gu = torch.zeros((batch, n1), dtype=torch.float32, device=dev)
+        ops.linear_dx_masked(att[1].weight, h2, gh2, ACT_RELU, z1, ACT_RELU, gz1, gu, length)
+        # layer 1 on the E-wide operand (gz1 already carries relu'(z1))
+        gwf = torch.zeros_like(wf)
+        ghrows = torch.empty_like(hrows)
+        ops.linear_bwd(hrows, wf[0], None, gz1, ACT_NONE, ghrows, gwf[0], zeros[id(b1)])
+        # u = t Wu^T + b1: dWu = gu^T t, and the target's gradient gains gu Wu on top of the fc input's share
+        gt = gfcin[:, dim:]
+        ops.linear_bwd(fcin[:, dim:], wf[1], None, gu, ACT_NONE, gt, gwf[1], None, accumulate_gx=True)
+        gw1 = zeros[id(w1)]                                   # dWa = dWh, dWb = dWh - dWu, dWc = dWu
+        gw1[:, :dim].copy_(gwf[0])
+        torch.sub(gwf[0], gwf[1], out=gw1[:, dim:2 * dim])
+        gw1[:, 2 * dim:].copy_(gwf[1])
+        gtable = zeros[id(table)]
+        ops.din_scatter_bwd(hist, table.shape[0], dim, ghrows, attn, gfcin[:, :dim], True, gtable)
+        ops.embed_bwd([ops.FieldSpec(_lib_field_id(), dim, dim, table=table, idx=target)], None, batch, gfcin,
+                      {id(table): gtable})
+        grads = [gtable]
+        for layer in att:
+            grads += [zeros[id(layer.weight)], zeros[id(layer.bias)]]
+        for gw, gb in fc_grads:
+            grads += [gw, gb]
+        return grads
+
     def run_forward(self, inputs, params):
         hist, target = inputs
         table = params[0]
+        if self._use_e_wide(hist, table.shape[1]):
+            return self._forward_e_wide(hist, target, params)
         att, fc = attention_layers(params[1:7]), fc_layers(params[7:13])
         batch, length = hist.shape
         dim = table.shape[1]
@@ -155,6 +236,8 @@ class DIN(SequenceModel):
 
     def run_backward(self, state, inputs, params, gprob):
         hist, target = inputs
+        if state[0] == "e":
+            return self._backward_e_wide(state, hist, target, params, gprob)
         att_acts, attn, fc_acts, w1f = state
         table = params[0]
         att, fc = attention_layers(params[1:7]), fc_layers(params[7:13])

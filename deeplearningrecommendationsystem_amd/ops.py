@@ -746,17 +746,58 @@ def cross_bwd(x0, u, gy, gu, gx0, gbias) -> None:
 # ---------------------------------------------------------------------------
 # DIN / DIEN sequence attention and GRU
 # ---------------------------------------------------------------------------
-def din_concat_fwd(table, hist, target, c, tvec, err_flag=None, pair: bool = False) -> None:
-    """attention operand per position: [h, h-t, t] (the reference's cat) or, ``pair``, [h, t]"""
+def linear_group_fwd(x, w, bias, res, group: int, act: int = ACT_NONE, out=None) -> torch.Tensor:
+    """out = act(x @ w.T + bias + res[row // group]): one residual row per ``group`` consecutive rows (DIN: the
+    per-sample term of the first attention layer on the E-wide operand)"""
+    x, w, res = _mat(x, "x"), _mat(w, "w"), _mat(res, "res")
+    m, k = x.shape
+    n = w.shape[0]
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    out = _mat(out, "out")
+    rc = _timed(f"linear_group_fwd[{m}x{n}x{k}]", lambda: (4 * (m * k + n * k + m * n + (m // group) * n), 2 * m * n * k),
+                _lib.load().ctr_linear_group_fwd, x.data_ptr(), _ld(x), w.data_ptr(), _ld(w), _lib.ptr(bias),
+                res.data_ptr(), _ld(res), group, out.data_ptr(), _ld(out), m, n, k, act, _lib.stream_ptr())
+    _lib.check(rc, "ctr_linear_group_fwd")
+    return out
+
+
+def linear_dx_masked(w, y, gy, act: int, xin, act_in: int, gx, gsum=None, group: int = 0) -> None:
+    """gx = ((gy * act'(y)) @ w) * act_in'(xin);  gsum[row // group] += gx[row] (optional)"""
+    w, gy, gx = _mat(w, "w"), _mat(gy, "gy"), _mat(gx, "gx")
+    m, n = gy.shape
+    k = w.shape[1]
+    rc = _timed(f"linear_dx_masked[{m}x{n}x{k}]",
+                lambda: (4 * (m * n * (2 if act != ACT_NONE else 1) + n * k + m * k * (2 if act_in != ACT_NONE else 1)),
+                         2 * m * n * k),
+                _lib.load().ctr_linear_dx_masked, w.data_ptr(), _ld(w), _lib.ptr(y), _ld(y) if y is not None else 0,
+                gy.data_ptr(), _ld(gy), act, _lib.ptr(xin), _ld(xin) if xin is not None else 0, act_in, gx.data_ptr(),
+                _ld(gx), _lib.ptr(gsum), _ld(gsum) if gsum is not None else 0, group, m, n, k, _lib.stream_ptr())
+    _lib.check(rc, "ctr_linear_dx_masked")
+
+
+def din_scatter_bwd(hist, vocab, dim, gh, attn, gpool, summed: bool, gtable) -> None:
+    """history positions' rows of the table gradient: gh + attn * gpool, scatter-added by hist ids"""
+    gh, gpool = _mat(gh, "gh"), _mat(gpool, "gpool")
+    batch, length = hist.shape
+    rc = _timed("din_scatter_bwd", lambda: (batch * length * (8 + 4 + 4 * dim * (3 if summed else 4)), 0),
+                _lib.load().ctr_din_scatter_bwd, hist.data_ptr(), vocab, batch, length, dim, gh.data_ptr(), _ld(gh),
+                attn.data_ptr(), gpool.data_ptr(), _ld(gpool), int(summed), gtable.data_ptr(), _lib.stream_ptr())
+    _lib.check(rc, "ctr_din_scatter_bwd")
+
+
+def din_concat_fwd(table, hist, target, c, tvec, err_flag=None, pair: bool = False, h_only: bool = False) -> None:
+    """attention operand per position: [h, h-t, t] (the reference's cat), ``pair``: [h, t], ``h_only``: [h]"""
     _lib.require_device(table, hist, target)
     c = _mat(c, "c")
     batch, length = hist.shape
     dim = table.shape[1]
-    width = 2 if pair else 3
+    width = 1 if h_only else (2 if pair else 3)
     rc = _timed("din_concat_fwd", lambda: (batch * length * (dim * 4 + 8 + 4 * width * dim) + batch * (8 + 8 * dim), 0),
                 _lib.load().ctr_din_concat_fwd, table.data_ptr(), table.shape[0], dim, hist.data_ptr(),
                 target.data_ptr(), batch, length, c.data_ptr(), _ld(c), _lib.ptr(tvec),
-                _ld(tvec) if tvec is not None else 0, _lib.DIN_PAIR if pair else _lib.DIN_TRIPLE,
+                _ld(tvec) if tvec is not None else 0,
+                _lib.DIN_H if h_only else (_lib.DIN_PAIR if pair else _lib.DIN_TRIPLE),
                 _lib.ptr(err_flag), _lib.stream_ptr())
     _lib.check(rc, "ctr_din_concat_fwd")
 

@@ -262,7 +262,7 @@ int ctr_cross_bwd(const float* x0, int64_t ldx0, const float* u, int64_t ldu, co
  *                   columns this way gets the same layer output from a 2E-wide operand (2/3 of
  *                   the bytes and flops of the largest GEMM of the step).
  *   h = table[hist[b,l]], t = table[target[b]];  tvec[b*ldt + 0:E] = t  (tvec may be NULL). */
-enum { CTR_DIN_TRIPLE = 0, CTR_DIN_PAIR = 1 };
+enum { CTR_DIN_TRIPLE = 0, CTR_DIN_PAIR = 1, CTR_DIN_H = 2 /* forward only: c[(b*len+l)*ldc + 0:E] = h, the E-wide operand */ };
 int ctr_din_concat_fwd(const float* table, int64_t vocab, int dim, const int64_t* hist, const int64_t* target,
                        int64_t batch, int len, float* c, int64_t ldc, float* tvec, int64_t ldt, int layout,
                        int32_t* err_flag, void* stream);
@@ -409,6 +409,32 @@ int ctr_bce_fwd(const float* prob, int64_t ldp, const float* target, int64_t ldt
 /* gprob[i*ldg] = (p_i - t_i) / max(p_i (1-p_i), 1e-12) * gloss[0] / n */
 int ctr_bce_bwd(const float* prob, int64_t ldp, const float* target, int64_t ldt, int64_t n,
                 const float* gloss, float* gprob, int64_t ldg, void* stream);
+
+/* history-position part of the DIN / DIEN table gradient for the E-wide operand (CTR_DIN_H):
+ *   gtable[hist[b,l], :] += gh[(b*len+l)*ldgh + 0:E] + attn[b*len+l] * gpool[(summed ? b : b*len+l)*ldgp + 0:E]
+ * gh = gradient of the attention MLP's E-wide input, gpool = gradient of the pooled output (model/din.py:47) or of
+ * the per-position outputs (model/dien.py:37).  fp32 atomics, row 0 pre-reduced per workgroup.  dim a power of two
+ * <= 256.  The target rows are scattered separately (ctr_embed_bwd with the target ids). */
+int ctr_din_scatter_bwd(const int64_t* hist, int64_t vocab, int64_t batch, int len, int dim, const float* gh,
+                        int64_t ldgh, const float* attn, const float* gpool, int64_t ldgp, int summed, float* gtable,
+                        void* stream);
+
+/* DIN attention on the E-wide operand (model/din.py:39-44: W1 [h, h-t, t] = (Wa+Wb) h + (Wc-Wb) t, so the
+ * first attention layer over all B*L positions only contracts the E columns of h; the per-sample term
+ * u[b] = (Wc-Wb) t_b + b1 is added per GROUP of L consecutive rows):
+ *   y[i, :] = act(x[i, :] W^T + bias + res[i / group, :])       (bias nullable; n <= 128) */
+int ctr_linear_group_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias /*nullable*/,
+                         const float* res, int64_t ldr, int group, float* y, int64_t ldy,
+                         int64_t m, int n, int k, int act, void* stream);
+/* input gradient of a layer with the activation mask of the layer BELOW folded into the write-back, plus the
+ * per-group column sums the grouped term above needs in backward:
+ *   gx[i, :] = ((gy[i, :] * act'(y[i, :])) W) * act_in'(xin[i, :])      (xin = this layer's input = the
+ *                                                                         previous layer's activation output)
+ *   gsum[i / group, :] += gx[i, :]                                      (nullable; fp32 atomics; group >= 32)
+ * k <= 128. */
+int ctr_linear_dx_masked(const float* w, int64_t ldw, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
+                         int act, const float* xin, int64_t ldxin, int act_in, float* gx, int64_t ldgx,
+                         float* gsum /*nullable*/, int64_t ldgsum, int group, int64_t m, int n, int k, void* stream);
 
 /* ---- opt-in sparse mode of the embedding gradient / optimizer (replaces, for the rows a
  * batch touches, what `optim.Adam(model.parameters(), lr, weight_decay=1e-5)` does to whole tables:

@@ -787,3 +787,54 @@ def test_adam_matches_torch_optim():
     for a, b in zip(ref_p, my_p):
         torch.testing.assert_close(b.detach().cpu(), a.detach(), rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(my_opt.state[b]["exp_avg_sq"].cpu(), ref_opt.state[a]["exp_avg_sq"], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("m,n,k,group", [(1000, 128, 64, 100), (4096, 64, 16, 32), (777, 128, 64, 37), (130, 32, 8, 130)])
+def test_linear_group_fwd_adds_one_residual_row_per_group(ops, m, n, k, group):
+    # DIN's first attention layer on the E-wide operand: y = relu(x W^T + u[row // L])
+    g = torch.Generator().manual_seed(m + n)
+    x = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    u = torch.randn((m + group - 1) // group, n, generator=g)
+    want = torch.relu(x.double() @ w.double().T + u.double().repeat_interleave(group, 0)[:m]).float()
+    got = ops.linear_group_fwd(x.to(DEV), w.to(DEV), None, u.to(DEV), group, ops.ACT_RELU).cpu()
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("m,n,k,group", [(1000, 64, 128, 100), (4096, 32, 64, 32), (777, 64, 128, 37), (260, 16, 32, 130)])
+def test_linear_dx_masked_and_group_sums(ops, m, n, k, group):
+    # gx = ((gy * relu'(y)) W) * relu'(xin), gsum[row // group] += gx[row]
+    g = torch.Generator().manual_seed(m + k)
+    w = torch.randn(n, k, generator=g) / n ** 0.5
+    y = torch.relu(torch.randn(m, n, generator=g))
+    xin = torch.relu(torch.randn(m, k, generator=g))
+    gy = torch.randn(m, n, generator=g)
+    want = ((gy.double() * (y > 0)) @ w.double()) * (xin > 0)
+    groups = (m + group - 1) // group
+    wsum = torch.zeros(groups, k, dtype=torch.float64).index_add_(0, torch.arange(m) // group, want)
+    gx = torch.full((m, k), float("nan"), device=DEV)
+    gsum = torch.zeros(groups, k, device=DEV)
+    ops.linear_dx_masked(w.to(DEV), y.to(DEV), gy.to(DEV), ops.ACT_RELU, xin.to(DEV), ops.ACT_RELU, gx, gsum, group)
+    torch.testing.assert_close(gx.cpu(), want.float(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gsum.cpu(), wsum.float(), rtol=1e-4, atol=1e-4)
+    # without the optional parts it is the plain input gradient
+    gx2 = torch.empty((m, k), device=DEV)
+    ops.linear_dx_masked(w.to(DEV), None, gy.to(DEV), ops.ACT_NONE, None, ops.ACT_NONE, gx2)
+    torch.testing.assert_close(gx2.cpu(), (gy.double() @ w.double()).float(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("batch,length,dim,summed", [(50, 100, 64, True), (33, 7, 16, False), (300, 40, 8, True)])
+def test_din_scatter_bwd_matches_index_add(ops, batch, length, dim, summed):
+    g = torch.Generator().manual_seed(batch)
+    vocab = 500
+    hist = torch.randint(0, vocab, (batch, length), generator=g)
+    hist[:, : length // 4] = 0                                  # padding id: the LDS-reduced row
+    gh = torch.randn(batch * length, dim, generator=g)
+    attn = torch.rand(batch, length, generator=g)
+    gpool = torch.randn(batch if summed else batch * length, dim, generator=g)
+    gp = gpool.repeat_interleave(length, 0) if summed else gpool
+    want = torch.zeros(vocab, dim, dtype=torch.float64)
+    want.index_add_(0, hist.reshape(-1), gh.double() + attn.reshape(-1, 1).double() * gp.double())
+    gt = torch.zeros(vocab, dim, device=DEV)
+    ops.din_scatter_bwd(hist.to(DEV), vocab, dim, gh.to(DEV), attn.to(DEV), gpool.to(DEV), summed, gt)
+    torch.testing.assert_close(gt.cpu(), want.float(), rtol=1e-4, atol=1e-4)

@@ -30,7 +30,7 @@ def test_embedding_stage_sparse_backward_lists_unique_rows_and_sums():
         assert torch.equal(rows.cpu(), torch.unique(idx[:, f]))
         ref = torch.zeros(vocab, dim, dtype=torch.float64)
         ref.index_add_(0, idx[:, f], 2.0 * gout[:, f * dim:(f + 1) * dim].double())
-        torch.testing.assert_close(vals.cpu().double(), ref[rows.cpu()], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(vals.cpu().double(), ref[rows.cpu()], rtol=1e-4, atol=1e-4)  # fp32 atomic sums of up to ~1200 rows
         # nothing outside the pending rows
         assert int((sparse.state_of(t).grad != 0).any(1).sum()) <= rows.numel()
     stage.zero_grad()
@@ -138,7 +138,9 @@ def test_sparse_mode_under_hipgraph_replay():
         ids_d, y_d = ids.to(DEV), y.to(DEV)
         if graphed:
             step = GraphedStep(module, BCELoss(), [ids_d], y_d)
-            module.zero_grad()      # the warm-up / capture passes left pending rows: start clean
+            from deeplearningrecommendationsystem_amd import sparse
+            sparse.discard(module.parameters())   # pending rows of the warm-up passes (NOT zero_grad: the dense
+            #                                       parameters' .grad are the graph's static tensors now)
         for _ in range(3):
             if graphed:
                 step()
