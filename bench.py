@@ -400,7 +400,8 @@ def main():
     from deeplearningrecommendationsystem_amd.optim import Adam
 
     if args.shard:
-        args.no_graph = True  # the exchange reads the per-rank counts on the host: not capturable
+        args.no_graph = True  # the row exchanges are RCCL collectives between launches: eager (the plan of an id tensor
+        #                       -- bucketing, id exchange, the one host read -- is built once and reused every step)
         if world == 1:  # a one-rank group: the same code path with an identity exchange
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")

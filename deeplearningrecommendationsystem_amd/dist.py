@@ -7,8 +7,9 @@ RCCL on ROCm; "gloo" in the CPU tests).  Nothing like it exists in the reference
   ONE all-reduce over a flat bucket (low MBs for every model of the zoo).
 * ``ShardedEmbedding`` -- model-parallel part for the 1e6..1e7-row tables: rows are dealt
   round-robin to the ranks (``owner = row % world``, ``local = row // world``: uniform load
-  whatever the id skew).  A lookup is: bucket ids by owner (HIP kernel) -> all_to_all of the
-  per-rank counts and of the ids -> local row gather (HIP kernel) -> all_to_all of the
+  whatever the id skew).  A lookup is: an ``ExchangePlan`` of the id tensor (bucket ids by owner with a HIP
+  kernel, all_to_all of the per-rank counts, one host read, all_to_all of the int32 local rows; cached per id
+  tensor and shared by every table indexed with it) -> local row gather (HIP kernel) -> all_to_all of the
   rows back -> un-permute into batch order (HIP kernel).  all-to-all is the right xGMI
   primitive: a full mesh of point-to-point links, all seven used concurrently, where a ring
   all-reduce would be bound by a single link.  Backward mirrors it and ends in a scatter-add
@@ -20,6 +21,7 @@ HIP one and needs the MI355X library like everything else in this package.
 """
 from __future__ import annotations
 
+import weakref
 from typing import Iterable, List, Optional
 
 import torch
@@ -125,19 +127,20 @@ class HipShardBackend:
     """the product backend: every step is a libctrhip launch on torch's current stream"""
 
     @staticmethod
-    def bucket(ids: torch.Tensor, world: int):
-        """-> (counts (world,) int64 on device, send (n,), perm (n,), inv (n,))"""
+    def bucket(ids: torch.Tensor, world: int, vocab: int):
+        """-> (counts (world + 1,) int64 on device -- the last slot counts ids outside [0, vocab) --,
+        send (n,) int32 local rows in bucket order, perm (n,), inv (n,))"""
         from . import _lib
         _lib.require_device(ids)
         n = ids.numel()
         dev = ids.device
-        counts = torch.empty(world, dtype=torch.int64, device=dev)
+        counts = torch.empty(world + 1, dtype=torch.int64, device=dev)
         cursor = torch.empty(world, dtype=torch.int64, device=dev)
-        send = torch.empty(n, dtype=torch.int64, device=dev)
+        send = torch.empty(n, dtype=torch.int32, device=dev)
         perm = torch.empty(n, dtype=torch.int64, device=dev)
         inv = torch.empty(n, dtype=torch.int64, device=dev)
-        rc = _lib.load().ctr_shard_bucket(_lib.ptr(ids) if n else None, n, world, counts.data_ptr(), cursor.data_ptr(),
-                                          _lib.ptr(send) if n else None, _lib.ptr(perm) if n else None,
+        rc = _lib.load().ctr_shard_bucket(_lib.ptr(ids) if n else None, n, world, vocab, counts.data_ptr(),
+                                          cursor.data_ptr(), _lib.ptr(send) if n else None, _lib.ptr(perm) if n else None,
                                           _lib.ptr(inv) if n else None, _lib.stream_ptr())
         _lib.check(rc, "ctr_shard_bucket")
         return counts, send, perm, inv
@@ -183,44 +186,98 @@ def _exchange(send: torch.Tensor, send_counts: List[int], recv_counts: List[int]
     return out
 
 
+class ExchangePlan:
+    """everything about ONE id tensor's lookup that does not depend on table contents: who owns which id
+    (bucket order, counts per rank) and which of this rank's rows the peers asked for.  Built once per id tensor
+    -- bucket kernel, count exchange, ONE host read of 2*world + 1 integers (the only sync), the id exchange
+    (int32 local rows on the wire) -- and reused by every table looked up with those ids (FFM: two field-aware
+    tables per id column) and by every later step that passes the same, unmodified tensor (the reference trains
+    full-batch on the same tensors every epoch, scripts/din.py:93-96): those steps run no bucketing, no id exchange
+    and no host sync at all, only the two row exchanges."""
+
+    __slots__ = ("send_counts", "recv_counts", "perm", "inv", "recv_ids", "n")
+
+
+# id(key tensor) -> (weak reference to it, {sub-key: ExchangePlan}).  Keyed by identity with a liveness check (a
+# WeakKeyDictionary would compare tensors with ==); the entry goes away with the tensor.
+_PLANS: dict = {}
+
+
+def _plans_of(anchor: torch.Tensor, create: bool):
+    entry = _PLANS.get(id(anchor))
+    if entry is not None and entry[0]() is anchor:
+        return entry[1]
+    if not create:
+        return None
+    key = id(anchor)
+    plans: dict = {}
+    _PLANS[key] = (weakref.ref(anchor, lambda _r, key=key: _PLANS.pop(key, None)), plans)
+    return plans
+
+
+def exchange_plan(ids: torch.Tensor, module: "ShardedEmbedding", key=None) -> ExchangePlan:
+    """``key`` = (tensor whose identity and version stand for the ids, hashable extra) when ``ids`` itself is a
+    temporary (FFM: ``x[:, 0].long()`` of the feature matrix ``x``); default: the id tensor itself"""
+    anchor, extra = (ids, None) if key is None else key
+    sub = (anchor._version, extra, id(module.group), module.world, module.num_embeddings, tuple(ids.shape))
+    plans = _plans_of(anchor, False)
+    if plans is not None and sub in plans:
+        return plans[sub]
+    be, group, world = module.backend, module.group, module.world
+    flat = ids.reshape(-1).contiguous()
+    counts, send_ids, perm, inv = be.bucket(flat, world, module.num_embeddings)
+    staged = _host_staged(counts, group)
+    mine = counts[:world].cpu() if staged else counts[:world].contiguous()
+    theirs = torch.empty_like(mine)
+    dist.all_to_all_single(theirs, mine, group=group)
+    both = torch.cat([counts.cpu() if staged else counts, theirs]).tolist()   # the one host read of the lookup
+    send_counts, bad, recv_counts = [int(c) for c in both[:world]], int(both[world]), [int(c) for c in both[world + 1:]]
+    if bad:
+        raise IndexError(f"index out of range in self ({bad} ids outside [0, {module.num_embeddings}))")
+    plan = ExchangePlan()
+    plan.send_counts, plan.recv_counts, plan.perm, plan.inv, plan.n = send_counts, recv_counts, perm, inv, flat.numel()
+    plan.recv_ids = _exchange(send_ids, send_counts, recv_counts, group).long()   # local rows the peers want
+    plans = _plans_of(anchor, True)
+    if len(plans) >= 8:
+        plans.clear()   # an id tensor modified in place over and over: keep the newest versions only
+    plans[sub] = plan
+    return plan
+
+
 class _ShardedLookup(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, weight, ids, module):
-        be, group, world = module.backend, module.group, module.world
-        flat = ids.reshape(-1).contiguous()
-        counts, send_ids, perm, inv = be.bucket(flat, world)
-        send_counts = [int(c) for c in counts.tolist()]                  # one host sync per lookup
-        if _host_staged(counts, group):
-            recv_counts_t = torch.empty(world, dtype=counts.dtype)
-            dist.all_to_all_single(recv_counts_t, counts.cpu(), group=group)
-        else:
-            recv_counts_t = torch.empty_like(counts)
-            dist.all_to_all_single(recv_counts_t, counts, group=group)
-        recv_counts = [int(c) for c in recv_counts_t.tolist()]
-        recv_ids = _exchange(send_ids, send_counts, recv_counts, group)   # local rows other ranks want
-        rows = be.gather_rows(weight, recv_ids)                           # this shard's rows
-        back = _exchange(rows, recv_counts, send_counts, group)          # my rows, bucket order
-        out = be.gather_rows(back, perm)                                  # batch order
-        ctx.module = module
-        ctx.send_counts, ctx.recv_counts = send_counts, recv_counts
-        ctx.save_for_backward(weight, recv_ids, inv)
-        return out.view(tuple(ids.shape) + (weight.shape[1],))
+    def forward(ctx, weight, module, plan, shape):
+        be, group = module.backend, module.group
+        rows = be.gather_rows(weight, plan.recv_ids)                                # this shard's rows
+        back = _exchange(rows, plan.recv_counts, plan.send_counts, group)          # my rows, bucket order
+        out = be.gather_rows(back, plan.perm)                                       # batch order
+        ctx.module, ctx.plan = module, plan
+        ctx.save_for_backward(weight)
+        return out.view(tuple(shape) + (weight.shape[1],))
 
     @staticmethod
     def backward(ctx, gout):
-        weight, recv_ids, inv = ctx.saved_tensors
-        be, group = ctx.module.backend, ctx.module.group
+        (weight,) = ctx.saved_tensors
+        module, plan = ctx.module, ctx.plan
+        be, group = module.backend, module.group
         g = gout.reshape(-1, weight.shape[1]).contiguous()
-        g_bucketed = be.gather_rows(g, inv)                                            # bucket order
-        g_owner = _exchange(g_bucketed, ctx.send_counts, ctx.recv_counts, group)      # to the owners
-        grad = torch.zeros_like(weight)
-        be.scatter_add_rows(grad, recv_ids, g_owner)
-        if ctx.module.average:
-            # every rank's loss is a mean over ITS samples and the replicated parameters are
-            # averaged over the ranks (GradBucket): the shard sums contributions of all ranks'
-            # samples, so the same global-mean gradient needs the 1/world here
-            grad.mul_(1.0 / ctx.module.world)
-        return grad, None, None
+        g_bucketed = be.gather_rows(g, plan.inv)                                         # bucket order
+        g_owner = _exchange(g_bucketed, plan.send_counts, plan.recv_counts, group)      # to the owners
+        if module.average:
+            # every rank's loss is a mean over ITS samples and the replicated parameters are averaged over the
+            # ranks (GradBucket): the shard sums contributions of all ranks' samples, so the same global-mean
+            # gradient needs the 1/world -- applied to the exchanged rows, not to the whole shard
+            g_owner.mul_(1.0 / module.world)
+        from . import sparse
+        st = sparse.state_of(weight) if weight.is_cuda else None
+        if st is not None:
+            # sparse mode: into the shard's persistent accumulation buffer, pending rows listed, no dense gradient
+            be.scatter_add_rows(st.grad, plan.recv_ids, g_owner)
+            sparse.mark([(weight, plan.recv_ids)])
+            return None, None, None, None
+        grad = torch.zeros_like(weight)   # dense semantics (the reference's optimizer sweeps whole tables)
+        be.scatter_add_rows(grad, plan.recv_ids, g_owner)
+        return grad, None, None, None
 
 
 class ShardedEmbedding(torch.nn.Module):
@@ -252,5 +309,16 @@ class ShardedEmbedding(torch.nn.Module):
         mine = full[self.rank::self.world]
         self.weight[:mine.shape[0]].copy_(mine)
 
-    def forward(self, ids: torch.Tensor) -> torch.Tensor:
-        return _ShardedLookup.apply(self.weight, ids, self)
+    def sparse_grads(self, enable: bool = True):
+        """opt-in sparse mode of the shard's gradient (sparse.py): backward lists the touched local rows instead of
+        returning a shard-sized dense gradient; train with this package's ``optim.Adam``"""
+        from . import sparse
+        if enable and sparse.state_of(self.weight) is None:
+            self.weight._ctr_sparse = sparse.SparseRows(self.weight)
+        elif not enable and sparse.state_of(self.weight) is not None:
+            del self.weight._ctr_sparse
+        return self
+
+    def forward(self, ids: torch.Tensor, plan_key=None) -> torch.Tensor:
+        plan = exchange_plan(ids, self, plan_key)
+        return _ShardedLookup.apply(self.weight, self, plan, ids.shape)

@@ -81,7 +81,9 @@ class SequenceModel(CtrModule):
         the exchange into the owners' shards"""
         batch, length = hist.shape
         ids = torch.cat([hist.reshape(-1), target.reshape(-1)])
-        rows = table_module(ids)
+        # the concatenation is a temporary: the exchange plan is keyed by the caller's tensors (same, unmodified
+        # (hist, target) next epoch -> no bucketing, no id exchange, no host sync)
+        rows = table_module(ids, plan_key=(hist, (id(target), target._version)))
         pos = torch.arange(batch * (length + 1), device=hist.device, dtype=torch.int64)
         return rows, pos[:batch * length].view(batch, length), pos[batch * length:]
 

@@ -69,7 +69,10 @@ class FFM(FeatureModel):
             uid, iid = feature_vector[:, 0].long(), feature_vector[:, 1].long()
             for k, name in enumerate(VECTORS):
                 if name in SHARDED:
-                    params[k] = getattr(self, name)(uid if name.startswith("userid") else iid)
+                    # the ids are a temporary of the feature matrix: its identity / version key the exchange plan,
+                    # which the two field-aware tables of an id column share (one id exchange per column)
+                    user = name.startswith("userid")
+                    params[k] = getattr(self, name)(uid if user else iid, plan_key=(feature_vector, 0 if user else 1))
         return self._run_model(feature_vector, params)
 
     def _specs(self, tables, dim):

@@ -368,13 +368,13 @@ int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* l
  * Row-sharded tables across the GPUs of a node (no counterpart in the reference,
  * which is single-device): owner(row) = row % world, local
  * row = row / world.  Buckets `n` global ids by owner ahead of the RCCL all-to-all:
- *   counts[w]  = ids owned by rank w                    (world int64, written)
- *   send[slot] = local row, buckets back to back in rank order
+ *   counts[w]  = ids owned by rank w, w < world; counts[world] = ids outside [0, vocab)  (world + 1 int64, written)
+ *   send[slot] = local row as int32 (the wire format), buckets back to back in rank order
  *   perm[i]    = slot of id i;  inv[slot] = i           (order inside a bucket is not fixed)
- * cursor: world int64 of scratch.  Negative ids count as row 0.
+ * cursor: world int64 of scratch.  Ids outside [0, vocab) travel as row 0 and are counted.
  * ---------------------------------------------------------------------- */
-int ctr_shard_bucket(const int64_t* ids, int64_t n, int world, int64_t* counts, int64_t* cursor,
-                     int64_t* send, int64_t* perm, int64_t* inv, void* stream);
+int ctr_shard_bucket(const int64_t* ids, int64_t n, int world, int64_t vocab, int64_t* counts, int64_t* cursor,
+                     int32_t* send, int64_t* perm, int64_t* inv, void* stream);
 
 /* ------------------------------------------------------------------------
  * Head folding: a linear layer W (n x k, bias b) whose output feeds ONLY a single-unit layer u is the
