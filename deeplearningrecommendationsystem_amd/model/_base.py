@@ -159,14 +159,36 @@ class FeatureModel(CtrModule):
         """(rows, width) buffer whose row stride is a multiple of 4 floats"""
         return torch.empty((rows, (width + 3) // 4 * 4), dtype=torch.float32, device=device)[:, :width]
 
-    def _rank_users(self, num_users, user_item, k):
-        """reference recommendation(): per-user scoring of the rows of the pandas
-        frame ``user_item`` (e.g. model/pnn.py:133-143)"""
-        rows = []
+    def _rank_users(self, num_users, user_item, k, chunk: int = 1 << 18):
+        """reference recommendation() (e.g. model/pnn.py:133-143): for every user, score the rows of the pandas
+        frame ``user_item`` that carry its id and return the positions (within those rows) of the k best.  The
+        reference filters the frame and calls forward once per user (943 host->device copies and forward calls);
+        here the frame goes to the device once, the rows are grouped by user with one stable sort, scored in
+        ``chunk``-row forward calls under no_grad, and ranked by one batched top-k."""
         dev = next(self.parameters()).device
+        feats = torch.as_tensor(user_item.values, dtype=torch.float32).to(dev)
+        uid = feats[:, 0].long()
+        order = torch.argsort(uid, stable=True)                 # rows of a user keep their frame order
+        feats = feats[order].contiguous()
+        counts = torch.bincount(uid, minlength=num_users)[:num_users]
+        scores = torch.empty(feats.shape[0], dtype=torch.float32, device=dev)
         with torch.no_grad():
-            for u in range(num_users):
-                feats = torch.tensor(user_item[user_item['user_id'] == u].values, dtype=torch.float32, device=dev)
-                scores = self.forward(feats)
-                rows.append(torch.topk(scores, k, dim=0).indices.view(1, -1).tolist()[0])
-        return np.array(rows)
+            for lo in range(0, feats.shape[0], chunk):
+                scores[lo:lo + chunk] = self.forward(feats[lo:lo + chunk]).view(-1)
+        return _segment_topk(scores, counts, k)
+
+
+def _segment_topk(scores: torch.Tensor, counts: torch.Tensor, k: int) -> np.ndarray:
+    """top-k positions inside consecutive segments of ``scores`` (segment u has ``counts[u]`` entries)"""
+    n_seg, longest = counts.numel(), int(counts.max()) if counts.numel() else 0
+    if k > int(counts.min()):
+        raise RuntimeError(f"selected index k out of range: a user has {int(counts.min())} candidate rows, k = {k}")
+    if int(counts.min()) == longest:                                     # the usual case: every user x every item
+        grid = scores.view(n_seg, longest)
+    else:
+        starts = torch.cumsum(counts, 0) - counts
+        pos = torch.arange(longest, device=scores.device).unsqueeze(0)
+        valid = pos < counts.unsqueeze(1)
+        grid = torch.full((n_seg, longest), float("-inf"), device=scores.device)
+        grid[valid] = scores[(starts.unsqueeze(1) + pos)[valid]]
+    return torch.topk(grid, k, dim=1).indices.cpu().numpy()

@@ -96,18 +96,28 @@ class SequenceModel(CtrModule):
         self._raise_if_bad_index()
         return out
 
-    def _rank_histories(self, num_users, num_items, hist_list, k):
-        """reference recommendation(): the user's whole history against every
-        item (model/din.py:55-66)"""
-        rows = []
+    def _rank_histories(self, num_users, num_items, hist_list, k, max_positions: int = 1 << 22):
+        """reference recommendation() (model/din.py:55-66): every user's WHOLE history (any length) against every
+        item.  The reference builds ``hist.repeat(num_items, 1)`` on the host and calls forward once per user;
+        here users are grouped by history length, a group's (user x item) samples go through forward together
+        (up to ``max_positions`` history positions per call), and the ranking is one top-k per group."""
         dev = next(self.parameters()).device
+        lengths = [len(hist_list[u]) for u in range(num_users)]
+        out = np.empty((num_users, k), dtype=np.int64)
         targets = torch.arange(0, num_items, device=dev)
+        by_len = {}
+        for u, n in enumerate(lengths):
+            by_len.setdefault(n, []).append(u)
         with torch.no_grad():
-            for u in range(num_users):
-                hist = torch.tensor(hist_list[u]).repeat(num_items, 1).to(dev)
-                scores = self.forward(hist, targets)
-                rows.append(torch.topk(scores, k, dim=0).indices.view(1, -1).tolist()[0])
-        return np.array(rows)
+            for n, users in by_len.items():
+                per_call = max(1, max_positions // max(1, n * num_items))
+                for lo in range(0, len(users), per_call):
+                    part = users[lo:lo + per_call]
+                    hist = torch.as_tensor(np.stack([np.asarray(hist_list[u], dtype=np.int64) for u in part]), device=dev)
+                    hist = hist.repeat_interleave(num_items, 0)                     # (users * items, n)
+                    scores = self.forward(hist, targets.repeat(len(part))).view(len(part), num_items)
+                    out[part] = torch.topk(scores, k, dim=1).indices.cpu().numpy()
+        return out
 
 
 class DIN(SequenceModel):

@@ -377,6 +377,24 @@ int ctr_shard_bucket(const int64_t* ids, int64_t n, int world, int64_t vocab, in
                      int32_t* send, int64_t* perm, int64_t* inv, void* stream);
 
 /* ------------------------------------------------------------------------
+ * The host work either side of the step, on the device.
+ * ctr_negative_sample (sampler/sampler.py:16-48): for every user u < num_users, num_negatives items drawn
+ * uniformly from [0, num_items), each redrawn while bit `item` of the user's row of `excluded`
+ * (num_users x words_per_user uint32, bit i of word i/32 = pair (u, i) observed) is set.
+ * users[u*num_negatives + j] = u, items[...] = the draw; counter-based generator: the sample depends on
+ * `seed` only.  *fail_flag (nullable) is raised if a slot found no free item in 16384 draws.
+ * ctr_assemble_features (data/reader.py:98-101): out[b, :] = [users[b], items[b] as floats,
+ * user_feat[users[b], :user_width], item_feat[items[b], :item_width]] -- the (B, 45) matrix of the feature
+ * models at user_width = 24 (age, 2 gender, 21 occupation columns), item_width = 19 (genre flags).
+ * ---------------------------------------------------------------------- */
+int ctr_negative_sample(const uint32_t* excluded, int64_t words_per_user, int64_t num_users, int64_t num_items,
+                        int num_negatives, uint64_t seed, int64_t* users, int64_t* items, int32_t* fail_flag,
+                        void* stream);
+int ctr_assemble_features(const int64_t* users, const int64_t* items, int64_t n, const float* user_feat,
+                          int user_width, int64_t num_users, const float* item_feat, int item_width,
+                          int64_t num_items, float* out, int64_t ldo, int32_t* err_flag, void* stream);
+
+/* ------------------------------------------------------------------------
  * Head folding: a linear layer W (n x k, bias b) whose output feeds ONLY a single-unit layer u is the
  * k-wide dot product  (h W^T + b).u + b2 == h.v + c,  v = W^T u,  c = b.u + b2.  NeuralCF ends like
  * that (model/neuralcf.py:27 linear, :50-56 cat + linear2): folding per step keeps the 8 -> mf_dim

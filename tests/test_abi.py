@@ -124,6 +124,8 @@ def _parse_header_prototypes():
                     kinds.append("ptr")
                 elif a.startswith("int64_t"):
                     kinds.append("i64")
+                elif a.startswith("uint64_t"):
+                    kinds.append("u64")
                 elif a.startswith("int ") or a.startswith("int32_t "):
                     kinds.append("int")
                 else:
@@ -161,6 +163,8 @@ def test_ctypes_signatures_match_header_prototypes(lib):
                 got.append("f32")
             elif a is ctypes.c_double:
                 got.append("f64")
+            elif a is ctypes.c_uint64:
+                got.append("u64")
             elif a is ctypes.POINTER(ctypes.c_int32):
                 got.append("i32*")
             elif a in (ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64)):

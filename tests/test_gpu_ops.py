@@ -717,16 +717,23 @@ def test_fused_mlp_matches_layerwise_and_fp64(ops, m, dims, acts_):
 def test_shard_bucket_kernel(n, world):
     from deeplearningrecommendationsystem_amd.dist import HipShardBackend
     g = torch.Generator().manual_seed(n + world)
-    ids = torch.randint(0, 1_000_000, (n,), generator=g)
-    counts, send, perm, inv = HipShardBackend.bucket(ids.to(DEV), world)
+    vocab = 1_000_000
+    ids = torch.randint(0, vocab, (n,), generator=g)
+    nbad = 0
+    if n >= 37:
+        ids[3], ids[11] = vocab + 5, -2                                      # out of range: counted, sent as row 0
+        nbad = 2
+    counts, send, perm, inv = HipShardBackend.bucket(ids.to(DEV), world, vocab)
     counts, send, perm, inv = counts.cpu(), send.cpu(), perm.cpu(), inv.cpu()
-    assert counts.tolist() == torch.bincount(ids % world, minlength=world).tolist()
+    good = torch.where((ids < 0) | (ids >= vocab), torch.zeros_like(ids), ids)
+    assert send.dtype == torch.int32                                     # the wire format
+    assert counts.tolist() == torch.bincount(good % world, minlength=world).tolist() + [nbad]
+    counts = counts[:world]
     assert sorted(perm.tolist()) == list(range(n))                       # a permutation
     assert torch.equal(inv[perm], torch.arange(n))                       # inv is its inverse
-    assert torch.equal(send[perm], ids // world)                         # slot holds the local row
-    starts = torch.cumsum(counts, 0) - counts
+    assert torch.equal(send[perm].long(), good // world)                 # slot holds the local row
     owner_of_slot = torch.bucketize(torch.arange(n), torch.cumsum(counts, 0), right=True)
-    assert torch.equal(owner_of_slot[perm], ids % world)                 # buckets are in rank order
+    assert torch.equal(owner_of_slot[perm], good % world)                # buckets are in rank order
 
 
 def test_sharded_embedding_single_rank_on_gpu():
@@ -838,3 +845,60 @@ def test_din_scatter_bwd_matches_index_add(ops, batch, length, dim, summed):
     gt = torch.zeros(vocab, dim, device=DEV)
     ops.din_scatter_bwd(hist.to(DEV), vocab, dim, gh.to(DEV), attn.to(DEV), gpool.to(DEV), summed, gt)
     torch.testing.assert_close(gt.cpu(), want.float(), rtol=1e-4, atol=1e-4)
+
+
+def test_device_negative_sampling_properties():
+    """sampler/sampler.py:16-48 on the device: num_negatives per user, none of them an observed pair, uniform over
+    the user's free items, reproducible per seed, accumulating across calls like the reference's instance"""
+    from deeplearningrecommendationsystem_amd.sampler import Sampler
+    nu, ni, neg = 50, 300, 2000
+    rng = np.random.default_rng(0)
+    excluded = set()
+    for u in range(nu):
+        for i in rng.choice(ni, size=100 + u, replace=False):
+            excluded.add((u, int(i)))
+    for i in range(ni - 3):
+        excluded.add((7, i))                                   # user 7 has three free items
+    s = Sampler(seed=3)
+    users, items, ratings = s.negative_sampling(nu, ni, excluded, neg, DEV)
+    assert users.shape == items.shape == ratings.shape == (nu * neg,) and not bool(ratings.any())
+    u, i = users.cpu().numpy(), items.cpu().numpy()
+    assert np.array_equal(u, np.repeat(np.arange(nu), neg))
+    assert not any((int(a), int(b)) in excluded for a, b in zip(u[::7], i[::7]))
+    ex = np.zeros((nu, ni), dtype=bool)
+    for a, b in excluded:
+        ex[a, b] = True
+    assert not ex[u, i].any()
+    assert set(i[u == 7]) == {ni - 3, ni - 2, ni - 1}
+    # uniform over the free items: chi-square of user 3's draws against a flat law
+    free = np.flatnonzero(~ex[3])
+    cnt = np.bincount(i[u == 3], minlength=ni)[free]
+    chi2 = ((cnt - neg / free.size) ** 2 / (neg / free.size)).sum()
+    assert chi2 < free.size + 6 * (2 * free.size) ** 0.5, chi2
+    # same seed -> same sample; the instance accumulates over calls (sampler.py:13-14)
+    u2, i2, _ = Sampler(seed=3).negative_sampling(nu, ni, excluded, neg, DEV)
+    assert torch.equal(i2, items)
+    u3, i3, r3 = s.negative_sampling(nu, ni, excluded, 5, DEV)
+    assert u3.numel() == nu * (neg + 5) and torch.equal(i3[:nu * neg], items)
+    df = Sampler(seed=4).negative_sampling2(nu, ni, excluded, 4, DEV)
+    assert list(df.columns) == ['user_id', 'item_id', 'rating'] and len(df) == nu * 4 and int(df['rating'].sum()) == 0
+
+
+def test_device_feature_assembly_equals_the_pandas_merges():
+    """data/reader.py:98-101 feature(): merge on user_id then on item_id (inner joins keep the left order)"""
+    import pandas as pd
+    from deeplearningrecommendationsystem_amd.data import FeatureAssembler
+    rng = np.random.default_rng(1)
+    nu, ni, n = 40, 60, 5000
+    user_data = pd.DataFrame(np.column_stack([np.arange(nu), rng.random(nu), rng.integers(0, 2, (nu, 23))]),
+                             columns=['user_id', 'age'] + [f'u{c}' for c in range(23)])
+    item_data = pd.DataFrame(np.column_stack([np.arange(ni), rng.integers(0, 2, (ni, 19))]),
+                             columns=['item_id'] + [f'g{c}' for c in range(19)])
+    user_data, item_data = user_data.sample(frac=1, random_state=0), item_data.sample(frac=1, random_state=1)  # any row order
+    pairs = pd.DataFrame({'user_id': rng.integers(0, nu, n), 'item_id': rng.integers(0, ni, n), 'rating': 1})
+    want = pd.merge(pd.merge(pairs, user_data, on='user_id'), item_data, on='item_id').drop('rating', axis=1)
+    fa = FeatureAssembler.from_frames(user_data, item_data, DEV)
+    got = fa.feature(torch.from_numpy(pairs['user_id'].values).to(DEV), torch.from_numpy(pairs['item_id'].values).to(DEV))
+    assert got.shape == (n, 45)
+    assert np.array_equal(got.cpu().numpy(), want.values.astype(np.float32))
+    fa.check_bad_index()
