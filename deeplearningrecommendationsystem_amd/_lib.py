@@ -15,7 +15,7 @@ import torch  # noqa: F401  (maps libamdhip64 first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTRHIP_LIB", os.path.join(_HERE, "libctrhip.so"))  # env override: A/B builds
-ABI_VERSION = 17
+ABI_VERSION = 19
 DIN_TRIPLE, DIN_PAIR, DIN_H = 0, 1, 2  # layouts of the DIN attention operand (include/ctrhip.h)
 
 CTR_MAX_FIELDS = 32
@@ -96,6 +96,8 @@ SIGNATURES = {
     "ctr_fields_fm_fwd": (_i, [_p, _l, _l, _i, _i, C.POINTER(_p), C.POINTER(_l), C.POINTER(_p), _p, _p, _l, _p, _l, _p, _p]),
     "ctr_fields_fm_bwd": (_i, [_p, _l, _l, _i, _i, C.POINTER(_l), _p, _l, _p, _l, _p, _l, C.POINTER(_p), C.POINTER(_p),
                                _p, _p, _l, _p]),
+    "ctr_ffm_fused_fwd": (_i, [_p, _l, _l, _i, C.POINTER(_p), _l, _l, _p, _p, _p, _p, _p, _l, _p, _l, _p, _p]),
+    "ctr_ffm_fused_bwd": (_i, [_p, _l, _l, _i, _p, _l, _l, _l, _p, _p, _l, _p, _l, _p, _p, _p, _p, _p, _l, _p, _l, _p]),
     "ctr_ffm_head_fwd": (_i, [_p, _l, _l, _i, _i, C.POINTER(C.c_int32), _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l,
                               _p, _p, _p, _l, _p, _p]),
     "ctr_ffm_head_bwd": (_i, [_p, _l, _l, _i, _i, C.POINTER(C.c_int32), _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l,

@@ -56,6 +56,8 @@ class FFM(FeatureModel):
         for name in ("user", "item"):
             xavier_normal_(getattr(self, name).weight.data)
 
+    fused_forward = True   # False: the two-launch forward of round 1 (embed_fwd + ffm_head_fwd), kept for A/B
+
     def _params(self):
         return [getattr(self, n).weight for n in VECTORS] + [self.user.weight, self.item.weight,
                                                               self.linear.weight, self.linear.bias]
@@ -91,8 +93,12 @@ class FFM(FeatureModel):
         tables, (user1, item1, lin_w, lin_b) = params[:12], params[12:16]
         batch, dim = x.shape[0], tables[0].shape[1]
         emb = torch.empty((batch, 12 * dim), dtype=torch.float32, device=x.device)
-        ops.embed_fwd(self._specs(tables, dim), x, batch, emb, self._flag)
         prob = torch.empty((batch, 1), dtype=torch.float32, device=x.device)
+        if self.fused_forward and not self.sharded and dim in (8, 16, 32, 64):
+            # gather, bags, the 15 dots and the head in one launch (csrc/ffm_fused.hip)
+            ops.ffm_fused_fwd(x, tables, user1, item1, lin_w, lin_b, emb, prob, self._flag)
+            return prob, (emb, prob)
+        ops.embed_fwd(self._specs(tables, dim), x, batch, emb, self._flag)
         ops.ffm_head_fwd(emb, 12, dim, PAIRS, x, user1, item1, lin_w, lin_b, prob, self._flag)
         return prob, (emb, prob)
 
@@ -112,8 +118,12 @@ class FFM(FeatureModel):
         else:
             zeros = ops.zero_grads(params)
         g_user1, g_item1, g_w, g_b = (zeros[id(t)] for t in (user1, item1, lin_w, lin_b))
-        ops.ffm_head_bwd(emb, 12, dim, PAIRS, x, user1, item1, lin_w, lin_b, prob, gprob.view(batch, 1),
-                         g_user1, g_item1, g_w, g_b, gemb)
+        if self.fused_forward and not self.sharded and dim in (8, 16, 32, 64):
+            ops.ffm_fused_bwd(x, emb, user1.shape[0], item1.shape[0], lin_w, prob, gprob.view(batch, 1), g_user1, g_item1,
+                              g_w, g_b, gemb)
+        else:
+            ops.ffm_head_bwd(emb, 12, dim, PAIRS, x, user1, item1, lin_w, lin_b, prob, gprob.view(batch, 1),
+                             g_user1, g_item1, g_w, g_b, gemb)
         tgrads = zeros
         ops.embed_bwd(self._specs(tables, dim), x, batch, gemb, tgrads)
         return [tgrads[id(t)] for t in tables] + [g_user1, g_item1, g_w, g_b]

@@ -645,6 +645,31 @@ def _pair_array(pairs):
     return (C.c_int32 * len(flat))(*flat)
 
 
+def ffm_fused_fwd(x, tables, user1, item1, lin_w, lin_b, emb, prob, err_flag=None) -> None:
+    """FFM forward in one launch: the 12 field-aware vectors into ``emb`` (B, 12k), the probability into ``prob``"""
+    x, emb, prob = _mat(x, "x"), _mat(emb, "emb"), _mat(prob, "prob")
+    _lib.require_device(user1, item1, lin_w, lin_b, *tables)
+    batch, dim = x.shape[0], tables[0].shape[1]
+    rc = _timed("ffm_fused_fwd", lambda: (4 * batch * (45 + 4 * dim + 2 + 12 * dim + 1), 2 * batch * (15 + 86) * dim),
+                _lib.load().ctr_ffm_fused_fwd, x.data_ptr(), _ld(x), batch, dim, _ptr_array(tables), user1.shape[0],
+                item1.shape[0], user1.data_ptr(), item1.data_ptr(), lin_w.data_ptr(), lin_b.data_ptr(), emb.data_ptr(),
+                _ld(emb), prob.data_ptr(), _ld(prob), _lib.ptr(err_flag), _lib.stream_ptr())
+    _lib.check(rc, "ctr_ffm_fused_fwd")
+
+
+def ffm_fused_bwd(x, emb, num_users, num_items, lin_w, prob, gprob, guser1, gitem1, glin_w, glin_b, gemb) -> None:
+    """backward of ``ffm_fused_fwd``'s head + dots: small gradients directly, ``gemb`` for the embedding backward"""
+    x, emb, prob, gprob, gemb = _mat(x, "x"), _mat(emb, "emb"), _mat(prob, "prob"), _mat(gprob, "gprob"), _mat(gemb, "gemb")
+    batch, dim = x.shape[0], emb.shape[1] // 12
+    ws = _scratch(emb.device)
+    rc = _timed("ffm_fused_bwd", lambda: (4 * batch * (45 + 24 * dim + 4), 4 * batch * 15 * dim),
+                _lib.load().ctr_ffm_fused_bwd, x.data_ptr(), _ld(x), batch, dim, emb.data_ptr(), _ld(emb), num_users,
+                num_items, lin_w.data_ptr(), prob.data_ptr(), _ld(prob), gprob.data_ptr(), _ld(gprob), _lib.ptr(guser1),
+                _lib.ptr(gitem1), _lib.ptr(glin_w), _lib.ptr(glin_b), gemb.data_ptr(), _ld(gemb), ws.data_ptr(),
+                ws.numel(), _lib.stream_ptr())
+    _lib.check(rc, "ctr_ffm_fused_bwd")
+
+
 def ffm_head_fwd(emb, nvec, dim, pairs, x, user1, item1, lin_w, lin_b, prob, err_flag=None) -> None:
     emb, prob = _mat(emb, "emb"), _mat(prob, "prob")
     batch = emb.shape[0]

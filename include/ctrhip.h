@@ -437,6 +437,29 @@ int ctr_din_scatter_bwd(const int64_t* hist, int64_t vocab, int64_t batch, int l
                         int64_t ldgh, const float* attn, const float* gpool, int64_t ldgp, int summed, float* gtable,
                         void* stream);
 
+/* FFM forward in one launch (model/ffm.py:46-86): x is the (batch, >= 45) feature matrix; tables[12] the
+ * field-aware tables in the order age_user, age_item, gender_user, gender_item, occupation_user, occupation_item,
+ * movie_user, movie_item, userid_user, userid_item, itemid_user, itemid_item (each (vocab, dim), dim in
+ * {8, 16, 32, 64}; the bag tables have 1 / 2 / 21 / 19 rows, model/ffm.py:11-26); user1 / item1 the (vocab, 1)
+ * bias tables, lin_w / lin_b the Linear(43, 1).  Writes emb (batch, 12*dim) -- the vectors, identical to what
+ * ctr_embed_fwd produces for the same field list, kept for the backward -- and
+ *   prob[b*ldp] = sigmoid(user1[u] + item1[i] + sum_c (x[b, 2+c] + cross) lin_w[c] + lin_b),
+ *   cross = the 15 dot products of ffm.py:62-80 summed left to right. */
+int ctr_ffm_fused_fwd(const float* x, int64_t ldx, int64_t batch, int dim, const float* const* tables,
+                      int64_t num_users, int64_t num_items, const float* user1, const float* item1,
+                      const float* lin_w, const float* lin_b, float* emb, int64_t lde, float* prob, int64_t ldp,
+                      int32_t* err_flag, void* stream);
+
+/* backward of ctr_ffm_fused_fwd's head and dot products from the emb it wrote: dz = gprob * prob (1 - prob);
+ * guser1[u] += dz, gitem1[i] += dz (fp32 atomics), glin_b += sum dz, glin_w[c] += sum dz (x[b,2+c] + cross)
+ * (fixed-order partials through the workspace, >= 1024 * 44 floats), and
+ * gemb[b, f*dim : (f+1)*dim] = dz * sum(lin_w) * (sum of the vectors paired with f in ffm.py:62-80), which
+ * ctr_embed_bwd then turns into the table gradients.  Any gradient pointer may be NULL. */
+int ctr_ffm_fused_bwd(const float* x, int64_t ldx, int64_t batch, int dim, const float* emb, int64_t lde,
+                      int64_t num_users, int64_t num_items, const float* lin_w, const float* prob, int64_t ldp,
+                      const float* gprob, int64_t ldgp, float* guser1, float* gitem1, float* glin_w, float* glin_b,
+                      float* gemb, int64_t ldg, float* workspace, int64_t workspace_floats, void* stream);
+
 /* DIN attention on the E-wide operand (model/din.py:39-44: W1 [h, h-t, t] = (Wa+Wb) h + (Wc-Wb) t, so the
  * first attention layer over all B*L positions only contracts the E columns of h; the per-sample term
  * u[b] = (Wc-Wb) t_b + b1 is added per GROUP of L consecutive rows):
