@@ -1009,6 +1009,10 @@ __device__ __forceinline__ void pair_commit(const float4 (&pre)[8], float* tile,
 
 constexpr int kPairWaves = 8, kPairs = 4;
 
+// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would
+// wait for the operand prefetch issued a moment earlier at every one of the 13 barriers of a tile
+__device__ __forceinline__ void pair_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <class S, int MAXT>
 __global__ void __launch_bounds__(64 * kPairWaves, 2)
 mlp_bwd_pair_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int64_t m, float* __restrict__ gx,
@@ -1100,12 +1104,12 @@ mlp_bwd_pair_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx
         hx_sum += pr[0] + __shfl_xor(pr[0], 16, 64);  // column c0 + (r & 15)
       }
     }
-    __syncthreads();
+    pair_barrier();
     if (S::ACT[last] != CTR_ACT_NONE && W == 1) {
       // gZ = gY * act'(Y) of the last layer, in place (a [32][nl <= 8] tile: one wave's worth of work)
       tile_mask<8, true>(tp, sa, d.l[last].y, d.l[last].ldy, row0, m, nl, d.l[last].div_n, S::ACT[last], lane);
     }
-    __syncthreads();
+    pair_barrier();
     auto layer = [&](auto lqv) __attribute__((always_inline)) {
       constexpr int li = last - (int)decltype(lqv)::value;
       LayerDesc L = d.l[li];
@@ -1133,7 +1137,7 @@ mlp_bwd_pair_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx
       } else {
         pair_issue<S::K[last]>(pre, xlast, ldxlast, (tile + tstride) * 32, m, lane, W);
       }
-      __syncthreads();
+      pair_barrier();
       // bias gradient: lane j sums column j of gZ over this wave's 16 rows
       if (lane < LN) {
         float t = 0.0f;
@@ -1178,7 +1182,7 @@ mlp_bwd_pair_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx
         }
       }
       // both waves are done reading X_l before anybody writes dX_l over it
-      __syncthreads();
+      pair_barrier();
       {
         const float* wl = s_w + L.w_off;
         constexpr int wsd = LK + 4;
@@ -1226,7 +1230,7 @@ mlp_bwd_pair_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx
           }
         }
       }
-      if constexpr (li > 0) __syncthreads();  // dX_l complete: it is the gZ of layer l - 1
+      if constexpr (li > 0) pair_barrier();  // dX_l complete: it is the gZ of layer l - 1
     };
     static_layers(layer, std::make_integer_sequence<int, S::kLayers>{});
   }
@@ -1565,11 +1569,20 @@ extern "C" int ctr_mlp_head_bwd(const float* x, int64_t ldx, int64_t m, const ct
   CTR_REQUIRE(workspace_floats >= grid * slab, CTR_ELIMIT);
   hipStream_t st = (hipStream_t)stream;
   const HeadBwdDesc hb{hg->gprob, hg->ldgprob, hg->prob, hg->ldprob, hg->x, hg->ldx, hg->w, hg->gx, hg->ldgx, hg->act};
-  static const bool pair_off = [] {
-    const char* e = getenv("CTR_MLP_PAIR");  // "0": the one-wave-per-tile kernel of round 1 (A/B switch)
-    return e && e[0] == '0';
+  // CTR_MLP_PAIR=1 selects the two-waves-per-tile kernel (A/B switch).  Measured on MI355X, batch 65536 (rocprofv3,
+  // profiles/r02_mlp_pair_ab.txt): 73.1 us against 72.3 us for the one-wave-per-tile kernel -- occupancy 2, 201
+  // registers, no scratch, barriers that wait on LDS only (not on the operand prefetch) -- and no gain.  PMC of the
+  // one-wave kernel (profiles/r02_mlp_pmc.txt): per wave 12.0 K VALU + 3.7 K SALU + 1.8 K LDS + 0.16 K VMEM instructions
+  // next to 728 MFMAs; at one issue per ~4 cycles that instruction stream alone is ~70 K cycles beside the 47 K
+  // cycles of MFMA issue: the kernel is bound by instruction ISSUE per SIMD (address arithmetic, accumulator
+  // moves, exec-mask bookkeeping), which two waves on the same SIMD share -- splitting a tile between them moves
+  // instructions from one wave to the other (plus the pair's bookkeeping) and leaves the SIMD's total unchanged.
+  // What has to shrink is the instruction count per tile, not the register footprint.  Kept as an A/B switch.
+  static const bool pair_on = [] {
+    const char* e = getenv("CTR_MLP_PAIR");
+    return e && e[0] == '1';
   }();
-  if (!pair_off) {
+  if (pair_on) {
     // two waves per row tile, eight per workgroup (same tiles per workgroup, same slab layout)
     const size_t lds_bytes = b.lds_bytes + sizeof(float) * (size_t)(kPairWaves - kWaves) * b.d.nsum;
     CTR_REQUIRE(lds_bytes + sizeof(StackDesc) <= 160 * 1024, CTR_ELIMIT);
