@@ -287,7 +287,8 @@ __device__ __forceinline__ void tile_load4(float* tile, int stride, const float*
 
 // the same tile in two halves: pre_issue puts the loads in flight into registers (<= 16
 // dwordx4 per lane for width <= 128), pre_commit parks them in LDS once they are needed
-template <bool FIXED>
+// FULLM: every tile the kernel touches has its 32 rows inside the batch (m % 32 == 0): no clamps, no selects
+template <bool FIXED, bool FULLM = false>
 __device__ __forceinline__ void pre_issue(float4 (&pre)[16], const float* __restrict__ src, int64_t ld, int64_t row0,
                                           int64_t m, int width, const CtrFastDiv& div_w4, int lane, bool live) {
   const int units = 8 * width;
@@ -297,10 +298,14 @@ __device__ __forceinline__ void pre_issue(float4 (&pre)[16], const float* __rest
     pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live && i < units) {
       const int rr = FIXED ? i / (width / 4) : (int)ctr_div((uint32_t)i, div_w4), c = (i - rr * (width / 4)) * 4;
-      // clamped address + select instead of a branch per load
-      const int64_t row = row0 + rr < m ? row0 + rr : m - 1;
-      const float4 v = *reinterpret_cast<const float4*>(src + row * ld + c);
-      if (row0 + rr < m) pre[u] = v;
+      if constexpr (FULLM) {
+        pre[u] = *reinterpret_cast<const float4*>(src + (row0 + rr) * ld + c);
+      } else {
+        // clamped address + select instead of a branch per load
+        const int64_t row = row0 + rr < m ? row0 + rr : m - 1;
+        const float4 v = *reinterpret_cast<const float4*>(src + row * ld + c);
+        if (row0 + rr < m) pre[u] = v;
+      }
     }
   }
 }
@@ -344,7 +349,7 @@ __device__ __forceinline__ void tile_load1(float* tile, int stride, const float*
 }
 
 // tile[r][c] *= act'(y[row0+r][c]) for a [32][width] tile (rows past m are zero already)
-template <int U, bool FIXED>
+template <int U, bool FIXED, bool FULLM = false>
 __device__ __forceinline__ void tile_mask(float* tile, int stride, const float* __restrict__ y, int64_t ld,
                                           int64_t row0, int64_t m, int width, const CtrFastDiv& div_w, int act,
                                           int lane) {
@@ -359,7 +364,7 @@ __device__ __forceinline__ void tile_mask(float* tile, int stride, const float* 
       off[u] = -1;
       if (i < units) {
         const int rr = FIXED ? i / width : (int)ctr_div((uint32_t)i, div_w), c = i - rr * width;
-        if (row0 + rr < m) {
+        if (FULLM || row0 + rr < m) {
           off[u] = rr * stride + c;
           v[u] = y[(row0 + rr) * ld + c];
         }
@@ -560,7 +565,22 @@ __device__ __forceinline__ void dx_chunk(const float* gt, int gstride, const flo
   }
 }
 
-template <class S, int MAXT, bool HEADB = false>
+// the same with ONE accumulator chain: a dependent chain of v_mfma_f32_32x32x2_f32 issues at its full rate (64-cycle
+// issue, 64-cycle dependent latency), and the second chain cost 16 zero moves + 16 accumulator reads + 16 adds per
+// column tile in a kernel that is bound by instruction issue (profiles/r02_mlp_pmc.txt)
+template <int STEPS>
+__device__ __forceinline__ void dx_chunk1(const float* gt, int gstride, const float* wl, int wstride, int col, int base,
+                                          int r, int h, floatx16& acc) {
+  float fa[16], fb[16];
+  read_kc<STEPS>(gt, gstride, r, base, h, fa);
+  const float* wp = wl + (base + STEPS * h) * wstride + col;
+#pragma unroll
+  for (int t = 0; t < STEPS; ++t) fb[t] = wp[t * wstride];
+#pragma unroll
+  for (int t = 0; t < STEPS; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[t], acc, 0, 0, 0);
+}
+
+template <class S, int MAXT, bool HEADB = false, bool FULLM = false>
 __global__ void __launch_bounds__(kThreads, S::kWavesPerSimd)
 mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int64_t m, const float* __restrict__ gy,
                int64_t ldgy, float* __restrict__ gx, int64_t ldgx, float* __restrict__ ws, int64_t slab,
@@ -624,16 +644,16 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
   const int64_t ldxlast = last > 0 ? d.l[last > 0 ? last - 1 : 0].ldy : ldx;
   if constexpr (kPre) {
     const int64_t t0 = (int64_t)blockIdx.x * kWaves + wave;
-    pre_issue<true>(pre, xlast, ldxlast, t0 * 32, m, S::K[S::kFixed ? S::kLayers - 1 : 0], d.l[last].div_k4, lane0,
+    pre_issue<true, FULLM>(pre, xlast, ldxlast, t0 * 32, m, S::K[S::kFixed ? S::kLayers - 1 : 0], d.l[last].div_k4, lane0,
                     t0 < tiles);
-    if (gvec) pre_issue<true>(gpre, gy, ldgy, t0 * 32, m, nl, div_last, lane0, t0 < tiles);
+    if (gvec) pre_issue<true, FULLM>(gpre, gy, ldgy, t0 * 32, m, nl, div_last, lane0, t0 < tiles);
   }
   for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += tstride) {
     const int64_t row0 = tile * 32;
     // fixed shape: every lane-derived LDS / global offset of the unrolled stack is loop
     // invariant, and hoisting those few hundred values out of the tile loop spills them.
     // Re-deriving them per tile costs a shift and an add each.
-    const bool full = row0 + 32 <= m;
+    const bool full = FULLM || row0 + 32 <= m;
     int lane = lane0;
     if constexpr (S::kFixed) asm volatile("" : "+v"(lane));
     const int r = lane & 31, h = lane >> 5;
@@ -644,7 +664,7 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
       // gradient of the extra columns (32 per half-wave), and the batch sums by a transposed reduction:
       // lane r ends up with column (r & 15) of each 16-column group, summed over the 32 rows
       const int64_t row = row0 + r;
-      const bool ok = row < m;
+      const bool ok = FULLM || row < m;
       float gz = 0.0f;
       if (ok) gz = hb.gprob[row * hb.ldgp] * ctr_act_grad(hb.prob[row * hb.ldp], hb.act);
 #pragma unroll
@@ -693,7 +713,7 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
       // gZ = gY * act'(Y) of the last layer, in place (rows past m stay zero)
       const int act_last = S::kFixed ? S::ACT[S::kFixed ? S::kLayers - 1 : 0] : d.l[last].act;
       if (act_last != CTR_ACT_NONE) {
-        tile_mask<8, S::kFixed>(tp, sa, d.l[last].y, d.l[last].ldy, row0, m, nl, div_last, act_last, lane);
+        tile_mask<8, S::kFixed, FULLM>(tp, sa, d.l[last].y, d.l[last].ldy, row0, m, nl, div_last, act_last, lane);
         __builtin_amdgcn_wave_barrier();
       }
     }
@@ -734,12 +754,12 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
             const int lp = li > 0 ? li - 1 : 0;
             const float* nsrc = lp > 0 ? d.l[lp > 0 ? lp - 1 : 0].y : x;
             const int64_t nld = lp > 0 ? d.l[lp > 0 ? lp - 1 : 0].ldy : ldx;
-            pre_issue<true>(pre, nsrc, nld, row0, m, S::K[S::kFixed ? lp : 0], d.l[lp].div_k4, lane, true);
+            pre_issue<true, FULLM>(pre, nsrc, nld, row0, m, S::K[S::kFixed ? lp : 0], d.l[lp].div_k4, lane, true);
           } else {
             const int64_t nt = tile + tstride;
-            pre_issue<true>(pre, xlast, ldxlast, nt * 32, m, S::K[S::kFixed ? S::kLayers - 1 : 0], d.l[last].div_k4, lane,
+            pre_issue<true, FULLM>(pre, xlast, ldxlast, nt * 32, m, S::K[S::kFixed ? S::kLayers - 1 : 0], d.l[last].div_k4, lane,
                             nt < tiles);
-            if (gvec) pre_issue<true>(gpre, gy, ldgy, nt * 32, m, nl, div_last, lane, nt < tiles);
+            if (gvec) pre_issue<true, FULLM>(gpre, gy, ldgy, nt * 32, m, nl, div_last, lane, nt < tiles);
           }
         } else {
           tile_load4<4, S::kFixed>(xt, xs, src, ld_in, row0, m, L.k, L.div_k4, lane);
@@ -814,20 +834,18 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
           if (li > 0) act_prev = S::kFixed ? S::ACT[S::kFixed && li > 0 ? li - 1 : 0] : d.l[li > 0 ? li - 1 : 0].act;
 #pragma unroll
           for (int ct = 0; ct < nkt; ++ct) {
-            floatx16 a, a1;
+            floatx16 a;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) a[e] = a1[e] = 0.0f;
+            for (int e = 0; e < 16; ++e) a[e] = 0.0f;
             const int col = 32 * ct + r;
             int base = 0;
 #pragma unroll
-            for (; base + 32 <= L.n; base += 32) dx_chunk<16>(gt, gs, wl, wsd, col, base, r, h, a, a1);
+            for (; base + 32 <= L.n; base += 32) dx_chunk1<16>(gt, gs, wl, wsd, col, base, r, h, a);
             const int rem = L.n - base;  // 0..31, the tile is zero-padded to a multiple of 8
-            if (rem > 24) dx_chunk<16>(gt, gs, wl, wsd, col, base, r, h, a, a1);
-            else if (rem > 16) dx_chunk<12>(gt, gs, wl, wsd, col, base, r, h, a, a1);
-            else if (rem > 8) dx_chunk<8>(gt, gs, wl, wsd, col, base, r, h, a, a1);
-            else if (rem > 0) dx_chunk<4>(gt, gs, wl, wsd, col, base, r, h, a, a1);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) a[e] += a1[e];
+            if (rem > 24) dx_chunk1<16>(gt, gs, wl, wsd, col, base, r, h, a);
+            else if (rem > 16) dx_chunk1<12>(gt, gs, wl, wsd, col, base, r, h, a);
+            else if (rem > 8) dx_chunk1<8>(gt, gs, wl, wsd, col, base, r, h, a);
+            else if (rem > 0) dx_chunk1<4>(gt, gs, wl, wsd, col, base, r, h, a);
             if (col < L.k) {
               if (li == 0) {
                 if (gx) {
@@ -1591,10 +1609,17 @@ extern "C" int ctr_mlp_head_bwd(const float* x, int64_t ldx, int64_t m, const ct
     hipLaunchKernelGGL((mlp_bwd_pair_kernel<NcfTowerShape, 12>), dim3((unsigned)grid), dim3(64 * kPairWaves), lds_bytes,
                        st, b.d, x, ldx, m, gx, ldgx, workspace, slab, hb);
   } else {
-    rc = allow_lds(mlp_bwd_kernel<NcfTowerShape, 12, true>, b.lds_bytes);
-    if (rc != CTR_OK) return rc;
-    hipLaunchKernelGGL((mlp_bwd_kernel<NcfTowerShape, 12, true>), dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, st,
-                       b.d, x, ldx, m, nullptr, 0, gx, ldgx, workspace, slab, hb);
+    if (m % 32 == 0) {  // every tile full (the BASELINE batch): the instantiation without row-range checks
+      rc = allow_lds(mlp_bwd_kernel<NcfTowerShape, 12, true, true>, b.lds_bytes);
+      if (rc != CTR_OK) return rc;
+      hipLaunchKernelGGL((mlp_bwd_kernel<NcfTowerShape, 12, true, true>), dim3((unsigned)grid), dim3(kThreads),
+                         b.lds_bytes, st, b.d, x, ldx, m, nullptr, 0, gx, ldgx, workspace, slab, hb);
+    } else {
+      rc = allow_lds(mlp_bwd_kernel<NcfTowerShape, 12, true>, b.lds_bytes);
+      if (rc != CTR_OK) return rc;
+      hipLaunchKernelGGL((mlp_bwd_kernel<NcfTowerShape, 12, true>), dim3((unsigned)grid), dim3(kThreads), b.lds_bytes,
+                         st, b.d, x, ldx, m, nullptr, 0, gx, ldgx, workspace, slab, hb);
+    }
   }
   rc = ctr_launch_status();
   if (rc != CTR_OK) return rc;
