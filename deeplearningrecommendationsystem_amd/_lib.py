@@ -15,7 +15,7 @@ import torch  # noqa: F401  (maps libamdhip64 first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTRHIP_LIB", os.path.join(_HERE, "libctrhip.so"))  # env override: A/B builds
-ABI_VERSION = 19
+ABI_VERSION = 20
 DIN_TRIPLE, DIN_PAIR, DIN_H = 0, 1, 2  # layouts of the DIN attention operand (include/ctrhip.h)
 
 CTR_MAX_FIELDS = 32
@@ -90,6 +90,8 @@ SIGNATURES = {
     "ctr_linear_bwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _p, _l, _i, _p, _l, _p, _l, _i, _i, _i, _p, _l, _p]),
     "ctr_allpairs_fwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _p]),
     "ctr_allpairs_bwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _p, _l, _i, _p]),
+    "ctr_fields_pairs_fwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _p]),
+    "ctr_fields_pairs_bwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _p, _l, _i, _p]),
     "ctr_fm_wide_fwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _p, _l, _p, _p]),
     "ctr_fm_wide_bwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _i, _i, _i, _i, _p, _l, _p, _l, _p, _p, _p, _l,
                              _p, _p, _p, _p, _p, _l, _i, _p, _l, _p]),

@@ -549,9 +549,13 @@ def allpairs_fwd(emb: torch.Tensor, nvec: int, dim: int, out: Optional[torch.Ten
     npairs = nvec * (nvec - 1) // 2
     if out is None:
         out = torch.empty((batch, npairs), dtype=torch.float32, device=emb.device)
+    many = nvec > 8 and dim in (8, 16, 32, 64)   # lane-group kernel (fields.hip) instead of the six-field LDS tiles
     rc = _timed("allpairs_fwd", lambda: (4 * batch * (nvec * dim + npairs), 2 * batch * npairs * dim),
-                _lib.load().ctr_allpairs_fwd, emb.data_ptr(), _ld(emb), batch, nvec, dim, out.data_ptr(), _ld(out),
-                _lib.stream_ptr())
+                _lib.load().ctr_fields_pairs_fwd if many else _lib.load().ctr_allpairs_fwd, emb.data_ptr(), _ld(emb),
+                batch, nvec, dim, out.data_ptr(), _ld(out), _lib.stream_ptr())
+    if many and rc in _REFUSED:
+        rc = _lib.load().ctr_allpairs_fwd(emb.data_ptr(), _ld(emb), batch, nvec, dim, out.data_ptr(), _ld(out),
+                                          _lib.stream_ptr())
     _lib.check(rc, "ctr_allpairs_fwd")
     return out
 
@@ -560,10 +564,14 @@ def allpairs_bwd(emb, nvec, dim, gp, gemb, accumulate: bool) -> None:
     emb, gp, gemb = _mat(emb, "emb"), _mat(gp, "gp"), _mat(gemb, "gemb")
     batch = emb.shape[0]
     npairs = nvec * (nvec - 1) // 2
+    many = nvec > 8 and dim in (8, 16, 32, 64)
     rc = _timed("allpairs_bwd", lambda: (4 * batch * ((2 + int(accumulate)) * nvec * dim + npairs),
                                          2 * batch * npairs * dim * 2),
-                _lib.load().ctr_allpairs_bwd, emb.data_ptr(), _ld(emb), batch, nvec, dim, gp.data_ptr(), _ld(gp),
-                gemb.data_ptr(), _ld(gemb), int(accumulate), _lib.stream_ptr())
+                _lib.load().ctr_fields_pairs_bwd if many else _lib.load().ctr_allpairs_bwd, emb.data_ptr(), _ld(emb),
+                batch, nvec, dim, gp.data_ptr(), _ld(gp), gemb.data_ptr(), _ld(gemb), int(accumulate), _lib.stream_ptr())
+    if many and rc in _REFUSED:
+        rc = _lib.load().ctr_allpairs_bwd(emb.data_ptr(), _ld(emb), batch, nvec, dim, gp.data_ptr(), _ld(gp),
+                                          gemb.data_ptr(), _ld(gemb), int(accumulate), _lib.stream_ptr())
     _lib.check(rc, "ctr_allpairs_bwd")
 
 

@@ -189,6 +189,17 @@ int ctr_fields_fm_bwd(const int64_t* idx, int64_t ldidx, int64_t batch, int nfie
                       float* const* gfirst /*nullable*/, float* gbias /*nullable*/, float* workspace,
                       int64_t workspace_floats, void* stream);
 
+/* the same two operations (same arguments, same results) for many vectors -- PNN over F id fields, 325 products at
+ * F = 26 (model/pnn.py:59-66 applied to F fields).  The pinned shape F = 26, dim = 16 with 16-byte aligned, 4-float
+ * padded prod / gp rows runs with all 26 vectors of a sample in the registers of a lane quad (forward 45 us,
+ * backward 102 us at batch 65536 against 132 / 275 us of ctr_allpairs_*).  Other shapes: forward through a
+ * wave-private LDS strip (dim in {8, 16, 32, 64}, F*dim floats x 256/dim samples <= 56 KB); backward returns
+ * CTR_ELIMIT with nothing enqueued and the caller uses ctr_allpairs_bwd. */
+int ctr_fields_pairs_fwd(const float* emb, int64_t lde, int64_t batch, int nfields, int dim,
+                         float* prod, int64_t ldp, void* stream);
+int ctr_fields_pairs_bwd(const float* emb, int64_t lde, int64_t batch, int nfields, int dim,
+                         const float* gp, int64_t ldgp, float* gemb, int64_t ldg, int accumulate, void* stream);
+
 /* DeepFM wide part + FM second order (model/deepfm.py:63,71-77):
  *   out[b*ldo] = user1[u] + item1[i] + (x[b, dense_col0..+ndense) . wide_w + wide_b)
  *               + 0.5 * sum_e[(sum_f v_fe)^2 - sum_f v_fe^2]

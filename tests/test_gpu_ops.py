@@ -902,3 +902,32 @@ def test_device_feature_assembly_equals_the_pandas_merges():
     assert got.shape == (n, 45)
     assert np.array_equal(got.cpu().numpy(), want.values.astype(np.float32))
     fa.check_bad_index()
+
+
+@pytest.mark.parametrize("nvec,dim,batch", [(26, 16, 1000), (12, 8, 333), (9, 32, 65), (26, 16, 1), (20, 64, 130)])
+def test_allpairs_many_vectors_lane_group_kernels(ops, nvec, dim, batch):
+    # PNN inner products over F id fields (model/pnn.py:59-66 pairing, i < j lexicographic) and their backward
+    g = torch.Generator().manual_seed(nvec * dim + batch)
+    emb = torch.randn(batch, nvec * dim, generator=g)
+    v = emb.double().view(batch, nvec, dim)
+    iu = torch.triu_indices(nvec, nvec, 1)
+    want = (v[:, iu[0]] * v[:, iu[1]]).sum(-1)
+    npairs = nvec * (nvec - 1) // 2
+    out = torch.full((batch, (npairs + 3) // 4 * 4), float("nan"), device=DEV)[:, :npairs]
+    ops.allpairs_fwd(emb.to(DEV), nvec, dim, out=out)
+    torch.testing.assert_close(out.cpu(), want.float(), rtol=1e-5, atol=1e-5)
+    gp = torch.randn(batch, npairs, generator=g)
+    gwant = torch.zeros(batch, nvec, dim, dtype=torch.float64)
+    gwant.index_add_(1, iu[0], gp.double().unsqueeze(-1) * v[:, iu[1]])
+    gwant.index_add_(1, iu[1], gp.double().unsqueeze(-1) * v[:, iu[0]])
+    base = torch.randn(batch, nvec * dim, generator=g)
+    # the coefficients once densely packed and once in a row padded to 16 bytes (what the models pass; the pinned
+    # 26 x 16 shape takes its register-resident kernel only then)
+    gp_pad = torch.full((batch, (npairs + 3) // 4 * 4), float("nan"), device=DEV)[:, :npairs]
+    gp_pad.copy_(gp)
+    for accumulate in (False, True):
+        for coef in (gp.to(DEV), gp_pad):
+            gemb = base.clone().to(DEV)
+            ops.allpairs_bwd(emb.to(DEV), nvec, dim, coef, gemb, accumulate)
+            ref = gwant.view(batch, -1) + (base.double() if accumulate else 0)
+            torch.testing.assert_close(gemb.cpu(), ref.float(), rtol=1e-5, atol=1e-4)
