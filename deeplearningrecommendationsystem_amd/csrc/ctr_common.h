@@ -135,7 +135,7 @@ int ctr_gemm_dlds_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, 
                       int64_t ldr, float* y, int64_t ldy, int64_t m, int n, int k, int act, hipStream_t st);
 int ctr_gemm_dlds_fwd_group(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* res,
                             int64_t ldr, int group, float* y, int64_t ldy, int64_t m, int n, int k, int act,
-                            hipStream_t st);
+                            hipStream_t st, uint32_t* mask = nullptr, int64_t ldmask = 0);
 // gemm_dlds_dw.hip: weight gradient with direct global->LDS operand loads
 bool ctr_gemm_dlds_dw_ok(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
                          const float* gw, int64_t ldgw, int64_t m, int n, int k, int act);
@@ -151,5 +151,5 @@ int ctr_n1_fwd(const float* x, int64_t ldx, const float* w, const float* bias, c
                int64_t ldy, int64_t m, int k, int act, hipStream_t st);
 int ctr_n1_bwd(const float* x, int64_t ldx, const float* w, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
                float* gx, int64_t ldgx, int accumulate_gx, float* gw, float* gb, int64_t m, int k, int act,
-               float* ws, int64_t ws_floats, hipStream_t st);
+               float* ws, int64_t ws_floats, hipStream_t st, int act_in = CTR_ACT_NONE);
 

@@ -215,22 +215,26 @@ pool_fwd_kernel(const SeqGeom g, const float* __restrict__ score, const float* _
 }
 
 // gscore[b,l] = a_l (ga_l - sum_k a_k ga_k),  ga_l = <gsrc_l, h_l>, gsrc_l = gout[b,:]
-// (summed) or gout[(b,l),:].  Two sweeps over the sample's rows (the second one hits
-// L2): the first forms sum_k a_k ga_k, the second recomputes ga_l bit-identically and
-// writes the result, so nothing is staged between lanes.
+// (summed) or gout[(b,l),:].  One sweep over the sample's rows when the ga_l of a sample fit the wave's strip of
+// LDS (len <= kPoolStage: 320 -> us on 32768 x 100 x 64, the second sweep missed L2 with 2048 waves x 25 KB in
+// flight); longer histories take a second sweep that recomputes ga_l bit-identically.
+constexpr int kPoolStage = 512;
 template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 pool_bwd_kernel(const SeqGeom g, const float* __restrict__ attn, const float* __restrict__ hsrc, int64_t ldh,
                 const float* __restrict__ gout, int64_t ldgo, int summed, float* __restrict__ gscore) {
+  __shared__ float s_ga[kBlock / 64][kPoolStage];
   const int lane = threadIdx.x & 63;
   const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   const int sub = lane % g.lpr, rsub = lane / g.lpr, rows_per_iter = 64 / g.lpr;
+  const bool staged = g.len <= kPoolStage;
+  float* mine = s_ga[threadIdx.x >> 6];
   for (int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; b < g.batch; b += waves) {
     const float* ab = attn + b * g.len;
     float* gs = gscore + b * g.len;
     float dotsum = 0.0f;
 #pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < (staged ? 1 : 2); ++pass) {
       int l0 = 0;
       if (g.dim <= g.lpr * VEC) {
         // single chunk per lane: four row groups in flight (see pool_fwd_kernel); per row the same dot product
@@ -258,10 +262,12 @@ pool_bwd_kernel(const SeqGeom g, const float* __restrict__ attn, const float* __
             float ga = ga4[u];
             for (int o = g.lpr >> 1; o > 0; o >>= 1) ga += __shfl_xor(ga, o, 64);
             if (l < g.len && sub == 0) {
-              if (pass == 0)
+              if (pass == 0) {
                 dotsum = fmaf(ab4[u], ga, dotsum);
-              else
+                if (staged) mine[l] = ga;
+              } else {
                 gs[l] = ab4[u] * (ga - dotsum);
+              }
             }
           }
         }
@@ -282,13 +288,21 @@ pool_bwd_kernel(const SeqGeom g, const float* __restrict__ attn, const float* __
         }
         for (int o = g.lpr >> 1; o > 0; o >>= 1) ga += __shfl_xor(ga, o, 64);
         if (l < g.len && sub == 0) {
-          if (pass == 0)
+          if (pass == 0) {
             dotsum = fmaf(ab[l], ga, dotsum);
-          else
+            if (staged) mine[l] = ga;
+          } else {
             gs[l] = ab[l] * (ga - dotsum);
+          }
         }
       }
       if (pass == 0) dotsum = ctr_wave_sum(dotsum);
+    }
+    if (staged) {
+      // the strip is the wave's own: its LDS writes are ordered before these reads, no workgroup barrier
+      __builtin_amdgcn_wave_barrier();
+      for (int l = lane; l < g.len; l += 64) gs[l] = ab[l] * (mine[l] - dotsum);
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }

@@ -35,6 +35,7 @@ struct DldsArgs {
   int64_t m; int n; int64_t k; int act;
   int res_group;        // > 1: residual row of output row i is i / res_group (one row per group of consecutive rows)
   CtrFastDiv res_div;
+  uint32_t* mask; int64_t ldmask;  // optional: bit (j & 31) of mask[i*ldmask + j/32] = (Y[i,j] > 0); needs n % 32 == 0
 };
 
 // s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
@@ -152,6 +153,24 @@ gemm_fwd_dlds_kernel(const DldsArgs a) {
       for (int c = 0; c < CH; ++c)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[n][c][e] = 0.0f;
+    // grouped residual (DIN: u[b] for the L rows of sample b): the wave's 32 rows lie in at most two groups, so a
+    // lane needs two values per column tile.  Requested here, in front of the contraction: a load issued in the
+    // epilogue is waited for together with the stores of the column tiles before it.
+    const bool grouped = a.res && a.res_group >= 32;
+    const int64_t first = i0 + 32 * wave;
+    int64_t edge = 0;
+    float r0v[NT], r1v[NT];
+    if (grouped) {
+      const int64_t g0 = (int64_t)ctr_div((uint32_t)(first < a.m ? first : a.m - 1), a.res_div);
+      edge = (g0 + 1) * a.res_group;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int64_t j = j0 + 32 * n + r;
+        const int64_t jc = j < a.n ? j : a.n - 1;
+        r0v[n] = ctr_ldg(a.res + g0 * a.ldr + jc);
+        r1v[n] = ctr_ldg(a.res + (edge < a.m ? g0 + 1 : g0) * a.ldr + jc);
+      }
+    }
     for (int ks = 0; ks < nk; ++ks) {
       // my loads of the slot to multiply have landed (only those of the next slot may be in flight),
       // then everybody's have, and everybody is done reading the stage that is refilled next
@@ -213,18 +232,11 @@ gemm_fwd_dlds_kernel(const DldsArgs a) {
 #pragma unroll
           for (int c = 1; c < CH; ++c) v[e] += acc[n][c][e];
         }
-        if (a.res && a.res_group >= 32) {
-          // grouped residual (DIN: u[b] for the L rows of sample b): the wave's 32 rows lie in at most two groups,
-          // so a lane needs two values of its column -- 2 loads instead of 16 (882 -> us on 3276800 x 128 x 64)
-          const int64_t first = i0 + 32 * wave;
-          const int64_t g0 = (int64_t)ctr_div((uint32_t)(first < a.m ? first : a.m - 1), a.res_div);
-          const int64_t edge = (g0 + 1) * a.res_group;
-          const float r0 = ctr_ldg(a.res + g0 * a.ldr + j);
-          const float r1 = ctr_ldg(a.res + (edge < a.m ? g0 + 1 : g0) * a.ldr + j);
+        if (grouped) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int64_t i = first + (e & 3) + 8 * (e >> 2) + 4 * h;
-            v[e] += i < edge ? r0 : r1;
+            v[e] += i < edge ? r0v[n] : r1v[n];
           }
         } else if (a.res) {
           // all 16 residual values in flight at once (the wait for them also drains the ring's loads)
@@ -238,11 +250,23 @@ gemm_fwd_dlds_kernel(const DldsArgs a) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) v[e] += rv[e];
         }
+        // sign bits of the outputs for the backward (1 bit instead of 4 bytes per element re-read there): a ballot
+        // per register gives the 32 columns of two rows; lane r of the first half-wave keeps the word of row r
+        // (register (r & 3) + 4 * (r >> 3), upper half of the ballot when r & 4).  n % 32 == 0: every lane is here.
+        uint32_t word = 0;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int64_t i = i0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (i < a.m) ctr_stg(a.y + i * a.ldy + j, ctr_act(v[e], a.act));
+          const float o = ctr_act(v[e], a.act);
+          if (i < a.m) ctr_stg(a.y + i * a.ldy + j, o);
+          if (a.mask) {
+            const uint64_t bal = __ballot(o > 0.0f);
+            const uint32_t cand = (r & 4) ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+            if (e == (r & 3) + 4 * (r >> 3)) word = cand;
+          }
         }
+        if (a.mask && h == 0 && i0 + 32 * wave + r < a.m)
+          a.mask[(i0 + 32 * wave + r) * a.ldmask + ((j0 + 32 * n) >> 5)] = word;
       }
     }
   }
@@ -256,7 +280,7 @@ bool ctr_gemm_dlds_ok(const float* x, int64_t ldx, const float* w, int64_t ldw, 
 
 static int launch_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* res,
                       int64_t ldr, float* y, int64_t ldy, int64_t m, int n, int k, int act, hipStream_t st,
-                      int res_group = 1) {
+                      int res_group = 1, uint32_t* mask = nullptr, int64_t ldmask = 0) {
   const int nt = n <= 32 ? 1 : (n <= 64 ? 2 : 4);
   const int64_t mtiles = ctr_ceil_div(m, kBM);
   const int64_t ny = ctr_ceil_div(n, 32 * nt);
@@ -265,8 +289,9 @@ static int launch_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, 
   if (gx < 1) gx = 1;
   CTR_REQUIRE(ny <= 65535, CTR_ELIMIT);
   CTR_REQUIRE(res_group >= 1 && (res_group == 1 || m < (1ll << 32)), CTR_ELIMIT);
+  CTR_REQUIRE(!mask || (n % 32 == 0 && ldmask >= n / 32), CTR_EINVAL);
   const DldsArgs a{x, ldx, w, ldw, bias, res, ldr, y, ldy, m, n, (int64_t)k, act, res_group,
-                   ctr_fastdiv((uint32_t)res_group)};
+                   ctr_fastdiv((uint32_t)res_group), mask, ldmask};
   const dim3 grid((unsigned)gx, (unsigned)ny);
   if (nt == 1) hipLaunchKernelGGL(gemm_fwd_dlds_kernel<1>, grid, dim3(kThreads), 0, st, a);
   else if (nt == 2) hipLaunchKernelGGL(gemm_fwd_dlds_kernel<2>, grid, dim3(kThreads), 0, st, a);
@@ -277,8 +302,8 @@ static int launch_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, 
 // Y = act(X W^T + b + R[row / group]): one residual row per `group` consecutive output rows
 int ctr_gemm_dlds_fwd_group(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* res,
                             int64_t ldr, int group, float* y, int64_t ldy, int64_t m, int n, int k, int act,
-                            hipStream_t st) {
-  return launch_fwd(x, ldx, w, ldw, bias, res, ldr, y, ldy, m, n, k, act, st, group);
+                            hipStream_t st, uint32_t* mask, int64_t ldmask) {
+  return launch_fwd(x, ldx, w, ldw, bias, res, ldr, y, ldy, m, n, k, act, st, group, mask, ldmask);
 }
 
 int ctr_gemm_dlds_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* res,
@@ -298,14 +323,17 @@ int ctr_gemm_dlds_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, 
   return launch_fwd(x, ldx, w, ldw, bias, res, ldr, y, ldy, m, n, k, act, st);
 }
 
-// C ABI (include/ctrhip.h): Y = act(X W^T + b + R[row / group])
+// C ABI (include/ctrhip.h): Y = act(X W^T + b + R[row / group]);  optional sign bits of Y for the backward
 extern "C" int ctr_linear_group_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
-                                    const float* res, int64_t ldr, int group, float* y, int64_t ldy, int64_t m, int n,
-                                    int k, int act, void* stream) {
+                                    const float* res, int64_t ldr, int group, float* y, int64_t ldy,
+                                    uint32_t* mask /*nullable*/, int64_t ldmask, int64_t m, int n, int k, int act,
+                                    void* stream) {
   CTR_REQUIRE(m >= 0 && n >= 1 && k >= 1, CTR_EINVAL);
   if (m == 0) return CTR_OK;
   CTR_REQUIRE(x && w && res && y && group >= 1 && ldx >= k && ldw >= k && ldy >= n && ldr >= n, CTR_EINVAL);
   CTR_REQUIRE(act >= CTR_ACT_NONE && act <= CTR_ACT_SIGMOID, CTR_EINVAL);
   CTR_REQUIRE(ctr_gemm_dlds_ok(x, ldx, w, ldw, m, n, k) && n <= 128, CTR_ELIMIT);  // one launch: no column split
-  return ctr_gemm_dlds_fwd_group(x, ldx, w, ldw, bias, res, ldr, group, y, ldy, m, n, k, act, (hipStream_t)stream);
+  CTR_REQUIRE(!mask || (n % 32 == 0 && ldmask >= n / 32), CTR_EINVAL);
+  return ctr_gemm_dlds_fwd_group(x, ldx, w, ldw, bias, res, ldr, group, y, ldy, m, n, k, act, (hipStream_t)stream, mask,
+                                 ldmask);
 }

@@ -33,6 +33,8 @@ struct DxArgs {
   // gsum[row / group]
   const float* xin; int64_t ldxin; int act_in;
   float* gsum; int64_t ldgsum; int group;
+  // instead of xin: the sign bits ctr_linear_group_fwd wrote (bit (c & 31) of xmask[i*ldxmask + c/32]); gx *= bit
+  const uint32_t* xmask; int64_t ldxmask;
 };
 
 template <int N>
@@ -151,6 +153,17 @@ gemm_dx_dlds_kernel(const DxArgs a) {
       for (int c = 0; c < CH; ++c)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[nb][c][e] = 0.0f;
+    // sign-bit words of this wave's 32 rows (lane r: row r, one word per column tile), requested in front of the
+    // contraction: a load issued in the epilogue is waited for together with the stores of the tiles before it
+    uint32_t mrow[NT];
+    if constexpr (EPI) {
+      if (a.xmask) {
+        const int64_t row = i0 + 32 * wave + r;
+#pragma unroll
+        for (int nb = 0; nb < NT; ++nb)
+          mrow[nb] = row < a.m ? __builtin_nontemporal_load(a.xmask + row * a.ldxmask + ((c0 >> 5) + nb)) : 0u;
+      }
+    }
     for (int ks = 0; ks < nk; ++ks) {
       if (t1 < mtiles) wait_vmcnt<kPerSlot>();
       else wait_vmcnt<0>();
@@ -210,10 +223,22 @@ gemm_dx_dlds_kernel(const DxArgs a) {
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
           const int col = c0 + 32 * (nb0 + q) + r;
+          if (a.xmask) {
+            // register e holds rows (e & 3) + 8 (e >> 2) [+ 4 in the upper half-wave]: their words sit in those
+            // lanes of mrow
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const int64_t i = first + (e & 3) + 8 * (e >> 2) + 4 * h;
-            xv[q][e] = (a.xin && i < a.m && col < a.k) ? ctr_ldg(a.xin + i * a.ldxin + col) : 1.0f;
+            for (int e = 0; e < 16; ++e) {
+              const int rho = (e & 3) + 8 * (e >> 2);
+              const uint32_t w0 = __builtin_amdgcn_readlane(mrow[nb0 + q], rho);
+              const uint32_t w1 = __builtin_amdgcn_readlane(mrow[nb0 + q], rho + 4);
+              xv[q][e] = (((h ? w1 : w0) >> r) & 1u) ? 1.0f : 0.0f;
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int64_t i = first + (e & 3) + 8 * (e >> 2) + 4 * h;
+              xv[q][e] = (a.xin && i < a.m && col < a.k) ? ctr_ldg(a.xin + i * a.ldxin + col) : 1.0f;
+            }
           }
         }
 #pragma unroll
@@ -227,7 +252,8 @@ gemm_dx_dlds_kernel(const DxArgs a) {
               v[e] = acc[nb][0][e];
 #pragma unroll
               for (int c = 1; c < CH; ++c) v[e] += acc[nb][c][e];
-              if (a.xin) v[e] *= ctr_act_grad(xv[q][e], a.act_in);
+              if (a.xmask) v[e] *= xv[q][e];
+              else if (a.xin) v[e] *= ctr_act_grad(xv[q][e], a.act_in);
             }
             float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
@@ -298,6 +324,7 @@ struct DxEpilogue {
   bool on = false;
   const float* xin = nullptr; int64_t ldxin = 0; int act_in = CTR_ACT_NONE;
   float* gsum = nullptr; int64_t ldgsum = 0; int group = 1;
+  const uint32_t* xmask = nullptr; int64_t ldxmask = 0;
 };
 
 static int launch_dx(const float* w, int64_t ldw, const float* y, int64_t ldy, const float* gy, int64_t ldgy, float* gx,
@@ -311,7 +338,7 @@ static int launch_dx(const float* w, int64_t ldw, const float* y, int64_t ldy, c
   if (gx_ < 1) gx_ = 1;
   CTR_REQUIRE(ny <= 65535, CTR_ELIMIT);
   const DxArgs a{gy, ldgy, act == CTR_ACT_NONE ? nullptr : y, ldy, w, ldw, gx, ldgx, m, n, k, accumulate,
-                 ep.xin, ep.ldxin, ep.act_in, ep.gsum, ep.ldgsum, ep.group};
+                 ep.xin, ep.ldxin, ep.act_in, ep.gsum, ep.ldgsum, ep.group, ep.xmask, ep.ldxmask};
   const dim3 grid((unsigned)gx_, (unsigned)ny);
 #define CTR_DX(NT_, ACT_)                                                                                  \
   do {                                                                                                     \
@@ -347,22 +374,25 @@ int ctr_gemm_dlds_dx(const float* w, int64_t ldw, const float* y, int64_t ldy, c
   return launch_dx(w, ldw, y, ldy, gy, ldgy, gx, ldgx, accumulate, m, n, k, act, st);
 }
 
-// C ABI (include/ctrhip.h): gX = ((gY * act'(Y)) W) * act_in'(Xin);  gsum[row / group, :] += gX[row, :]
+// C ABI (include/ctrhip.h): gX = ((gY * act'(Y)) W) * act_in'(Xin)  [or * sign bit of Xin];  gsum[row / group, :] += gX[row, :]
 extern "C" int ctr_linear_dx_masked(const float* w, int64_t ldw, const float* y, int64_t ldy, const float* gy,
-                                    int64_t ldgy, int act, const float* xin, int64_t ldxin, int act_in, float* gx,
-                                    int64_t ldgx, float* gsum, int64_t ldgsum, int group, int64_t m, int n, int k,
-                                    void* stream) {
+                                    int64_t ldgy, int act, const float* xin, int64_t ldxin, int act_in,
+                                    const uint32_t* xmask /*nullable*/, int64_t ldxmask, float* gx, int64_t ldgx,
+                                    float* gsum, int64_t ldgsum, int group, int64_t m, int n, int k, void* stream) {
   CTR_REQUIRE(m >= 0 && n >= 1 && k >= 1, CTR_EINVAL);
   if (m == 0) return CTR_OK;
   CTR_REQUIRE(w && gy && gx && ldw >= k && ldgy >= n && ldgx >= k, CTR_EINVAL);
   CTR_REQUIRE(act >= CTR_ACT_NONE && act <= CTR_ACT_SIGMOID && act_in >= CTR_ACT_NONE && act_in <= CTR_ACT_SIGMOID, CTR_EINVAL);
   CTR_REQUIRE(act == CTR_ACT_NONE || (y && ldy >= n), CTR_EINVAL);
-  CTR_REQUIRE(act_in == CTR_ACT_NONE || (xin && ldxin >= k), CTR_EINVAL);
+  CTR_REQUIRE(act_in == CTR_ACT_NONE || xmask || (xin && ldxin >= k), CTR_EINVAL);
+  CTR_REQUIRE(!xmask || (act_in == CTR_ACT_RELU && k % 32 == 0 && ldxmask >= k / 32), CTR_EINVAL);  // bits = relu'(xin)
   CTR_REQUIRE(!gsum || (group >= 32 && ldgsum >= k), CTR_EINVAL);  // a wave's 32 rows span at most two groups
   CTR_REQUIRE(ctr_gemm_dlds_dx_ok(w, ldw, y, ldy, gy, ldgy, m, n, k, act) && k <= 128, CTR_ELIMIT);
   DxEpilogue ep;
   ep.on = true;
-  ep.xin = act_in == CTR_ACT_NONE ? nullptr : xin;
+  ep.xin = (act_in == CTR_ACT_NONE || xmask) ? nullptr : xin;
+  ep.xmask = xmask;
+  ep.ldxmask = ldxmask;
   ep.ldxin = ldxin;
   ep.act_in = act_in;
   ep.gsum = gsum;

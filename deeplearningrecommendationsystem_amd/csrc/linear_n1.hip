@@ -100,6 +100,7 @@ struct N1BwdArgs {
   float* gw; float* gb;
   int64_t m; int k; int act; int lpr;
   float* ws;  // per-workgroup partials [gridDim.x][k+1] (weights then bias), or NULL -> atomics
+  int act_in;  // != NONE: gx *= act_in'(x) -- x is the previous layer's activation output (gx may be x itself)
 };
 
 // U > 1: the row needs a single chunk per lane (k <= lpr * VEC) and U rows are in flight per
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(kBlock) n1_bwd_kernel(const N1BwdArgs a) {
         if (!ok) gz[u] = 0.0f;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) xv[u][v] = pv[u][v] = 0.0f;
-        if (live && need_w) {
+        if (live && (need_w || a.act_in != CTR_ACT_NONE)) {
           if (VEC == 4) {
             const float4 t = *reinterpret_cast<const float4*>(a.x + rc * a.ldx + c);
             xv[u][0] = t.x; xv[u][1] = t.y; xv[u][2] = t.z; xv[u][VEC - 1] = t.w;
@@ -161,13 +162,17 @@ __global__ void __launch_bounds__(kBlock) n1_bwd_kernel(const N1BwdArgs a) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) wacc[0][v] = fmaf(gz[u], xv[u][v], wacc[0][v]);
         if (live && a.gx && r < a.m) {
-          if (VEC == 4) {
-            *reinterpret_cast<float4*>(a.gx + r * a.ldgx + c) =
-                make_float4(fmaf(gz[u], wv[0], pv[u][0]), fmaf(gz[u], wv[1], pv[u][1]), fmaf(gz[u], wv[2], pv[u][2]),
-                            fmaf(gz[u], wv[VEC - 1], pv[u][VEC - 1]));
-          } else {
-            a.gx[r * a.ldgx + c] = fmaf(gz[u], wv[0], pv[u][0]);
+          float o[VEC];
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            float t = gz[u] * wv[v];
+            if (a.act_in != CTR_ACT_NONE) t *= ctr_act_grad(xv[u][v], a.act_in);
+            o[v] = t + pv[u][v];
           }
+          if (VEC == 4)
+            *reinterpret_cast<float4*>(a.gx + r * a.ldgx + c) = make_float4(o[0], o[1], o[2], o[VEC - 1]);
+          else
+            a.gx[r * a.ldgx + c] = o[0];
         }
       }
     }
@@ -275,7 +280,7 @@ int ctr_n1_fwd(const float* x, int64_t ldx, const float* w, const float* bias, c
 
 int ctr_n1_bwd(const float* x, int64_t ldx, const float* w, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
                float* gx, int64_t ldgx, int accumulate_gx, float* gw, float* gb, int64_t m, int k, int act,
-               float* ws, int64_t ws_floats, hipStream_t st) {
+               float* ws, int64_t ws_floats, hipStream_t st, int act_in) {
   const bool vec = k % 4 == 0 && (!x || (ldx % 4 == 0 && ctr_aligned16(x))) && (!w || ctr_aligned16(w)) &&
                    (!gx || (ldgx % 4 == 0 && ctr_aligned16(gx)));
   const int units = vec ? k / 4 : k;
@@ -286,8 +291,10 @@ int ctr_n1_bwd(const float* x, int64_t ldx, const float* w, const float* y, int6
   if (grid > 1024) grid = 1024;
   const bool slabs = gw && ws && ws_floats >= (int64_t)grid * (k + 1) && grid > 8;
   if ((gw || gb) && !slabs && grid > 128) grid = 128;  // same-address atomics serialise: keep the chains short
-  N1BwdArgs a{x, ldx, w, y, ldy, gy, ldgy, gx, ldgx, accumulate_gx, gw, gb, m, k, act, lpr, slabs ? ws : nullptr};
+  N1BwdArgs a{x, ldx, w, y, ldy, gy, ldgy, gx, ldgx, accumulate_gx, gw, gb, m, k, act, lpr, slabs ? ws : nullptr,
+              act_in};
   const bool single = (vec ? 4 : 1) * lpr >= k && x && w;  // one chunk per lane: 4 rows in flight
+  if (act_in != CTR_ACT_NONE && !single) return CTR_ELIMIT;  // the masked form exists for one chunk per lane only
   if (vec && single)
     hipLaunchKernelGGL((n1_bwd_kernel<4, 4>), dim3(grid), dim3(kBlock), 0, st, a);
   else if (vec)
@@ -303,4 +310,20 @@ int ctr_n1_bwd(const float* x, int64_t ldx, const float* w, const float* y, int6
   segs.s[0] = CtrSegment{0, k, gw};
   segs.s[1] = CtrSegment{k, 1, gb};
   return ctr_reduce_segments(ws, grid, k + 1, segs, st);
+}
+
+// C ABI (include/ctrhip.h): backward of a single-unit layer y = x w^T + b whose input x is the previous layer's
+// activation output, with that activation's derivative folded in:
+//   gx = (gy w) * act_in'(x)   (gx may be x itself: every element is read, then written, by the same lane)
+//   gw += gy^T x,  gb += sum gy
+extern "C" int ctr_linear_n1_bwd_masked(const float* x, int64_t ldx, const float* w, const float* gy, int64_t ldgy,
+                                        int act_in, float* gx, int64_t ldgx, float* gw, float* gb, int64_t m, int k,
+                                        float* workspace, int64_t workspace_floats, void* stream) {
+  CTR_REQUIRE(m >= 0 && k >= 1, CTR_EINVAL);
+  if (m == 0) return CTR_OK;
+  CTR_REQUIRE(x && w && gy && gx && ldx >= k && ldgx >= k && ldgy >= 1, CTR_EINVAL);
+  CTR_REQUIRE(act_in >= CTR_ACT_NONE && act_in <= CTR_ACT_SIGMOID, CTR_EINVAL);
+  CTR_REQUIRE(ctr_n1_supported(k), CTR_ELIMIT);
+  return ctr_n1_bwd(x, ldx, w, nullptr, 0, gy, ldgy, gx, ldgx, 0, gw, gb, m, k, CTR_ACT_NONE, workspace,
+                    workspace_floats, (hipStream_t)stream, act_in);
 }

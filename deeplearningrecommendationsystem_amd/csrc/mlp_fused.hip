@@ -538,6 +538,175 @@ mlp_fwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
   }
 }
 
+// ------------------------------------------------------------------ forward, eight waves per workgroup
+// The same stack walk with TWO waves per SIMD for a fixed shape whose first layer is the wide one (NeuralCF: 128
+// inputs).  PMC of the 4-wave kernel on that tower (profiles/r02_mlp_pmc.txt): a wave lives 89 k cycles, its
+// matrix instructions account for 24 k and nothing overlaps them -- it is alone on its SIMD, because the 32 x 132
+// input tile of layer 0 makes a wave's LDS strip 25 KB.  Here layer 0 takes its A operand straight from global
+// memory in fragment order (row r, columns 32c + 16h .. +15: four dwordx4 per contraction chunk, the registers
+// that held the prefetched tile anyway), so the strip only holds the narrow activations (13 KB) and eight waves
+// plus the weights fit the CU.
+constexpr int kWavesDirect = 8;
+
+template <class S>
+struct DirectLayout {
+  static constexpr int width(bool a) {   // tile A holds outputs of odd layers, tile B of even layers
+    int w = 8;
+    for (int i = 0; i < S::kLayers; ++i)
+      if (((i & 1) != 0) == a) w = S::N[i] > w ? S::N[i] : w;
+    return w;
+  }
+  static constexpr int sa() { return width(true) + 4; }
+  static constexpr int sb() { return width(false) + 4; }
+  static constexpr size_t lds_bytes() {
+    return sizeof(float) * (size_t)(Layout<S, false>::wfloats() + kWavesDirect * 32 * (sa() + sb()) + kSlack);
+  }
+};
+
+template <class S, bool HEAD>
+__global__ void __launch_bounds__(64 * kWavesDirect)
+mlp_fwd_direct_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int64_t m, const HeadDesc hd) {
+  static_assert(S::kFixed && S::K[0] % 32 == 0 && S::K[0] <= 128, "layer 0: whole 32-index chunks in registers");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ StackDesc s_desc;
+  for (int i = threadIdx.x; i < (int)(sizeof(StackDesc) / 4); i += blockDim.x)
+    reinterpret_cast<uint32_t*>(&s_desc)[i] = reinterpret_cast<const uint32_t*>(&dk)[i];
+  using Y = Layout<S, false>;
+  using D = DirectLayout<S>;
+  constexpr int sa = D::sa(), sb = D::sb(), nlayers = S::kLayers, wfloats = Y::wfloats();
+  constexpr int kChunks0 = S::K[0] / 32;
+  float* s_w = lds;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* ta = lds + wfloats + wave * 32 * (sa + sb);
+  float* tb = ta + 32 * sa;
+  const int r = lane & 31, h = lane >> 5;
+  __shared__ float s_hw[HEAD ? kHeadMax : 1];
+  constexpr int nlast = S::N[S::kLayers - 1];
+  const int64_t tiles = (m + 31) / 32;
+  const int64_t tstride = (int64_t)gridDim.x * kWavesDirect;
+  // the first tile's operand rows are requested before the weights are staged
+  float4 pre[4 * kChunks0];
+  auto fetch = [&](int64_t tl) {
+    const int64_t row = tl * 32 + r;
+    const bool live = tl < tiles && row < m;
+    const float* src = x + (live ? row : 0) * ldx + 16 * h;
+#pragma unroll
+    for (int c = 0; c < kChunks0; ++c)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        pre[4 * c + v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) pre[4 * c + v] = *reinterpret_cast<const float4*>(src + 32 * c + 4 * v);
+      }
+  };
+  fetch((int64_t)blockIdx.x * kWavesDirect + wave);
+  __syncthreads();
+  const StackDesc& d = s_desc;
+  float hc = 0.0f;
+  if constexpr (HEAD) {
+    for (int i = threadIdx.x; i < hd.p + nlast; i += blockDim.x) s_hw[i] = hd.w[i];
+    hc = hd.c[0];
+  }
+  stage_weights(s_w, d, true);
+  __syncthreads();
+
+  for (int64_t tile = (int64_t)blockIdx.x * kWavesDirect + wave; tile < tiles; tile += tstride) {
+    const int64_t row0 = tile * 32;
+    float4 xe[HEAD ? 8 : 1];
+    if constexpr (HEAD) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = 8 * u + 4 * h;
+        xe[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < hd.p && row0 + r < m) xe[u] = *reinterpret_cast<const float4*>(hd.x + (row0 + r) * hd.ldx + c);
+      }
+    }
+    auto layer = [&](auto liv) __attribute__((always_inline)) {
+      constexpr int li = decltype(liv)::value;
+      LayerDesc L = d.l[li];
+      pin_shape<S, false>(L, li);
+      const float* wl = s_w + L.w_off;
+      constexpr int ws = S::K[li] + 4;
+      constexpr int nct = (S::N[li] + 31) / 32;
+      const float* xin = (li & 1) ? tb : ta;     // layer li > 0 reads what layer li - 1 wrote
+      float* xout = (li & 1) ? ta : tb;
+      constexpr int sin = (li & 1) ? sb : sa, sout = (li & 1) ? sa : sb;
+#pragma unroll
+      for (int ct = 0; ct < nct; ++ct) {
+        floatx16 a, a1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a[e] = a1[e] = 0.0f;
+        const int j = 32 * ct + r;
+        if constexpr (li == 0) {
+#pragma unroll
+          for (int c = 0; c < kChunks0; ++c) {
+            float fb[16];
+            read_kc<16>(wl, ws, j, 32 * c, h, fb);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const float4 q = pre[4 * c + v];
+              a = __builtin_amdgcn_mfma_f32_32x32x2f32(q.x, fb[4 * v + 0], a, 0, 0, 0);
+              a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q.y, fb[4 * v + 1], a1, 0, 0, 0);
+              a = __builtin_amdgcn_mfma_f32_32x32x2f32(q.z, fb[4 * v + 2], a, 0, 0, 0);
+              a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q.w, fb[4 * v + 3], a1, 0, 0, 0);
+            }
+          }
+        } else {
+          constexpr int k = S::K[li];
+          int base = 0;
+#pragma unroll
+          for (; base + 32 <= k; base += 32) fwd_chunk<16>(xin, sin, wl, ws, j, base, r, h, a, a1);
+          constexpr int rem = k % 32;  // 0, 8, 16 or 24
+          if constexpr (rem == 8) fwd_chunk<4>(xin, sin, wl, ws, j, base, r, h, a, a1);
+          else if constexpr (rem == 16) fwd_chunk<8>(xin, sin, wl, ws, j, base, r, h, a, a1);
+          else if constexpr (rem == 24) fwd_chunk<12>(xin, sin, wl, ws, j, base, r, h, a, a1);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a[e] += a1[e];
+        if (j < S::N[li]) {
+          const float bias = s_w[L.b_off + j];
+          float* yp = L.y + (row0 + 4 * h) * L.ldy + j;
+          float* xo = xout + 4 * h * sout + j;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) a[e] = ctr_act(a[e] + bias, S::ACT[li]);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) xo[((e & 3) + 8 * (e >> 2)) * sout] = a[e];
+          if (row0 + 32 <= m) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ctr_stg(yp + ((e & 3) + 8 * (e >> 2)) * L.ldy, a[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              if (row0 + (e & 3) + 8 * (e >> 2) + 4 * h < m) ctr_stg(yp + ((e & 3) + 8 * (e >> 2)) * L.ldy, a[e]);
+          }
+        }
+      }
+      if constexpr (li == 0) fetch(tile + tstride);  // layer 0 is through with the registers
+      __builtin_amdgcn_wave_barrier();
+    };
+    static_layers(layer, std::make_integer_sequence<int, S::kLayers>{});
+    if constexpr (HEAD) {
+      const float* fin = ((nlayers - 1) & 1) ? ta : tb;
+      constexpr int fs = ((nlayers - 1) & 1) ? sa : sb;
+      float acc = 0.0f;
+#pragma unroll
+      for (int j = h; j < nlast; j += 2) acc = fmaf(fin[r * fs + j], s_hw[hd.p + j], acc);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = 8 * u + 4 * h;
+        if (c < hd.p) {
+          acc = fmaf(xe[u].x, s_hw[c], acc);
+          acc = fmaf(xe[u].y, s_hw[c + 1], acc);
+          acc = fmaf(xe[u].z, s_hw[c + 2], acc);
+          acc = fmaf(xe[u].w, s_hw[c + 3], acc);
+        }
+      }
+      acc += __shfl_xor(acc, 32, 64);
+      if (h == 0 && row0 + r < m) hd.out[(row0 + r) * hd.ldout] = ctr_act(acc + hc, hd.act);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 // ------------------------------------------------------------------ backward
 // KS-mode fragment: values tile[(base + STEPS*h + t) * stride + col], t < STEPS
 template <int STEPS>
@@ -1457,6 +1626,18 @@ static int mlp_fwd_impl(const float* x, int64_t ldx, int64_t m, const ctr_mlp_la
     CTR_REQUIRE(head->p == 0 || (ctr_aligned16(head->x) && head->ldx % 4 == 0), CTR_EALIGN);
     hd = HeadDesc{head->x, head->ldx, head->p, head->w, head->c, head->out, head->ldout, head->act};
     if (matches<NcfTowerShape, false>(layers, nlayers, b.d)) {
+      static const bool four = [] { const char* e = getenv("CTR_MLP_FWD_WAVES"); return e && e[0] == '4'; }();
+      if (!four) {  // two waves per SIMD (see mlp_fwd_direct_kernel); CTR_MLP_FWD_WAVES=4 keeps the A/B alive
+        constexpr size_t bytes = DirectLayout<NcfTowerShape>::lds_bytes();
+        static_assert(bytes + sizeof(StackDesc) + sizeof(float) * kHeadMax <= 160 * 1024, "eight strips + weights fit the CU");
+        rc = allow_lds(mlp_fwd_direct_kernel<NcfTowerShape, true>, bytes);
+        if (rc != CTR_OK) return rc;
+        int64_t g8 = ctr_ceil_div(tiles, kWavesDirect);
+        if (g8 > 256) g8 = 256;
+        hipLaunchKernelGGL((mlp_fwd_direct_kernel<NcfTowerShape, true>), dim3((unsigned)g8), dim3(64 * kWavesDirect), bytes,
+                           st, b.d, x, ldx, m, hd);
+        return ctr_launch_status();
+      }
       rc = allow_lds(mlp_fwd_kernel<NcfTowerShape, true>, b.lds_bytes);
       if (rc != CTR_OK) return rc;
       hipLaunchKernelGGL((mlp_fwd_kernel<NcfTowerShape, true>), dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, st, b.d,

@@ -176,16 +176,23 @@ class DIN(SequenceModel):
         fcin = torch.empty((batch, 2 * dim), dtype=torch.float32, device=dev)
         ops.din_concat_fwd(table, hist, target, hrows, fcin[:, dim:], self._flag, h_only=True)
         u = ops.linear_fwd(fcin[:, dim:], wf[1], att[0].bias)                       # (B, n1)
-        z1 = ops.linear_group_fwd(hrows, wf[0], None, u, length, ACT_RELU)          # (B*L, n1)
+        # the ReLU sign bits of z1 travel to the backward as 1 bit per element when the width allows whole words
+        n1 = w1.shape[0]
+        bits = torch.empty((batch * length, n1 // 32), dtype=torch.int32, device=dev) if n1 % 32 == 0 else None
+        z1 = ops.linear_group_fwd(hrows, wf[0], None, u, length, ACT_RELU, sign_bits=bits)   # (B*L, n1)
         h2 = ops.linear_fwd(z1, att[1].weight, att[1].bias, ACT_RELU)
         score = ops.linear_fwd(h2, att[2].weight, att[2].bias, ACT_NONE)
         attn = torch.empty((batch, length), dtype=torch.float32, device=dev)
         ops.din_pool_fwd(score, hrows, batch, length, dim, attn, fcin[:, :dim], summed=True)
         fc_acts = ops.mlp_fwd(fcin, fc)
-        return fc_acts[-1], ("e", hrows, z1, h2, attn, fc_acts, wf)
+        return fc_acts[-1], ("e", hrows, z1, h2, attn, fc_acts, wf, bits, [False])
 
     def _backward_e_wide(self, state, hist, target, params, gprob):
-        _, hrows, z1, h2, attn, fc_acts, wf = state
+        _, hrows, z1, h2, attn, fc_acts, wf, bits, spent = state
+        if spent[0]:
+            raise RuntimeError("DIN backward overwrites its saved activations: run the forward again before a second "
+                               "backward (retain_graph is not supported)")
+        spent[0] = True
         table = params[0]
         att, fc = attention_layers(params[1:7]), fc_layers(params[7:13])
         w1, b1 = att[0].weight, att[0].bias
@@ -197,13 +204,15 @@ class DIN(SequenceModel):
         fc_grads, gfcin = ops.mlp_bwd(fc_acts, fc, gprob, None, zeros=zeros)
         gscore = torch.empty((batch * length, 1), dtype=torch.float32, device=dev)
         ops.din_pool_bwd(attn, hrows, batch, length, dim, gfcin[:, :dim], True, gscore)
-        # layer 3 (n2 -> 1), layer 2 (n1 -> n2, ReLU)
-        gh2 = torch.empty_like(h2)
-        ops.linear_bwd(h2, att[2].weight, None, gscore, ACT_NONE, gh2, zeros[id(att[2].weight)], zeros[id(att[2].bias)])
-        ops.linear_bwd(z1, att[1].weight, h2, gh2, ACT_RELU, None, zeros[id(att[1].weight)], zeros[id(att[1].bias)])
+        # layer 3 (n2 -> 1) with layer 2's ReLU derivative folded in: h2 is overwritten by the pre-activation
+        # gradient of layer 2, so neither layer-2 kernel below reads an activation to mask with
+        gz2 = h2
+        ops.linear_n1_bwd_masked(h2, att[2].weight, gscore, ACT_RELU, gz2, zeros[id(att[2].weight)],
+                                 zeros[id(att[2].bias)])
+        ops.linear_bwd(z1, att[1].weight, None, gz2, ACT_NONE, None, zeros[id(att[1].weight)], zeros[id(att[1].bias)])
         gz1 = torch.empty_like(z1)
         gu = torch.zeros((batch, n1), dtype=torch.float32, device=dev)
-        ops.linear_dx_masked(att[1].weight, h2, gh2, ACT_RELU, z1, ACT_RELU, gz1, gu, length)
+        ops.linear_dx_masked(att[1].weight, None, gz2, ACT_NONE, z1, ACT_RELU, gz1, gu, length, sign_bits=bits)
         # layer 1 on the E-wide operand (gz1 already carries relu'(z1))
         gwf = torch.zeros_like(wf)
         ghrows = torch.empty_like(hrows)

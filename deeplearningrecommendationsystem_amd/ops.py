@@ -779,34 +779,66 @@ def cross_bwd(x0, u, gy, gu, gx0, gbias) -> None:
 # ---------------------------------------------------------------------------
 # DIN / DIEN sequence attention and GRU
 # ---------------------------------------------------------------------------
-def linear_group_fwd(x, w, bias, res, group: int, act: int = ACT_NONE, out=None) -> torch.Tensor:
+def linear_group_fwd(x, w, bias, res, group: int, act: int = ACT_NONE, out=None, sign_bits=None) -> torch.Tensor:
     """out = act(x @ w.T + bias + res[row // group]): one residual row per ``group`` consecutive rows (DIN: the
-    per-sample term of the first attention layer on the E-wide operand)"""
+    per-sample term of the first attention layer on the E-wide operand).  ``sign_bits``: an int32 (m, n/32) tensor
+    that receives bit (j & 31) of word j // 32 = (out[i, j] > 0) -- the ReLU derivative for ``linear_dx_masked``."""
     x, w, res = _mat(x, "x"), _mat(w, "w"), _mat(res, "res")
     m, k = x.shape
     n = w.shape[0]
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=x.device)
     out = _mat(out, "out")
-    rc = _timed(f"linear_group_fwd[{m}x{n}x{k}]", lambda: (4 * (m * k + n * k + m * n + (m // group) * n), 2 * m * n * k),
+    if sign_bits is not None:
+        _lib.require_device(sign_bits)
+        if sign_bits.dtype != torch.int32 or sign_bits.dim() != 2 or sign_bits.stride(1) != 1 or n % 32 or \
+                sign_bits.shape[0] != m or sign_bits.shape[1] < n // 32:
+            raise ValueError("linear_group_fwd: sign_bits must be an int32 (m, n/32) tensor with n % 32 == 0")
+    rc = _timed(f"linear_group_fwd[{m}x{n}x{k}]",
+                lambda: (4 * (m * k + n * k + m * n + (m // group) * n) + (m * n // 8 if sign_bits is not None else 0),
+                         2 * m * n * k),
                 _lib.load().ctr_linear_group_fwd, x.data_ptr(), _ld(x), w.data_ptr(), _ld(w), _lib.ptr(bias),
-                res.data_ptr(), _ld(res), group, out.data_ptr(), _ld(out), m, n, k, act, _lib.stream_ptr())
+                res.data_ptr(), _ld(res), group, out.data_ptr(), _ld(out), _lib.ptr(sign_bits),
+                sign_bits.stride(0) if sign_bits is not None else 0, m, n, k, act, _lib.stream_ptr())
     _lib.check(rc, "ctr_linear_group_fwd")
     return out
 
 
-def linear_dx_masked(w, y, gy, act: int, xin, act_in: int, gx, gsum=None, group: int = 0) -> None:
-    """gx = ((gy * act'(y)) @ w) * act_in'(xin);  gsum[row // group] += gx[row] (optional)"""
+def linear_dx_masked(w, y, gy, act: int, xin, act_in: int, gx, gsum=None, group: int = 0, sign_bits=None) -> None:
+    """gx = ((gy * act'(y)) @ w) * act_in'(xin);  gsum[row // group] += gx[row] (optional).  With ``sign_bits`` (what
+    ``linear_group_fwd`` wrote for xin, act_in = ReLU) xin is not read and may be None."""
     w, gy, gx = _mat(w, "w"), _mat(gy, "gy"), _mat(gx, "gx")
     m, n = gy.shape
     k = w.shape[1]
+    if sign_bits is not None:
+        _lib.require_device(sign_bits)
+        if sign_bits.dtype != torch.int32 or sign_bits.dim() != 2 or sign_bits.stride(1) != 1 or \
+                sign_bits.shape[0] != m or sign_bits.shape[1] * 32 < k:
+            raise ValueError("linear_dx_masked: sign_bits must be an int32 (m, k/32) tensor")
+        xin = None
+    mask_bytes = (m * k // 8) if sign_bits is not None else (4 * m * k if act_in != ACT_NONE else 0)
     rc = _timed(f"linear_dx_masked[{m}x{n}x{k}]",
-                lambda: (4 * (m * n * (2 if act != ACT_NONE else 1) + n * k + m * k * (2 if act_in != ACT_NONE else 1)),
-                         2 * m * n * k),
+                lambda: (4 * (m * n * (2 if act != ACT_NONE else 1) + n * k + m * k) + mask_bytes, 2 * m * n * k),
                 _lib.load().ctr_linear_dx_masked, w.data_ptr(), _ld(w), _lib.ptr(y), _ld(y) if y is not None else 0,
-                gy.data_ptr(), _ld(gy), act, _lib.ptr(xin), _ld(xin) if xin is not None else 0, act_in, gx.data_ptr(),
+                gy.data_ptr(), _ld(gy), act, _lib.ptr(xin), _ld(xin) if xin is not None else 0, act_in,
+                _lib.ptr(sign_bits), sign_bits.stride(0) if sign_bits is not None else 0, gx.data_ptr(),
                 _ld(gx), _lib.ptr(gsum), _ld(gsum) if gsum is not None else 0, group, m, n, k, _lib.stream_ptr())
     _lib.check(rc, "ctr_linear_dx_masked")
+
+
+def linear_n1_bwd_masked(x, w, gy, act_in: int, gx, gw=None, gb=None) -> None:
+    """backward of the single-unit layer y = x @ w.T + b whose input x is the previous layer's activation output:
+    gx = (gy @ w) * act_in'(x) (``gx`` may be ``x`` itself), gw += gy.T @ x, gb += gy.sum()"""
+    x, w, gy, gx = _mat(x, "x"), _mat(w, "w"), _mat(gy, "gy"), _mat(gx, "gx")
+    m, k = x.shape
+    if w.shape[0] != 1 or gy.shape != (m, 1) or gx.shape != (m, k):
+        raise ValueError("linear_n1_bwd_masked: w must be (1, k), gy (m, 1), gx (m, k)")
+    ws = _scratch(x.device) if gw is not None else None
+    rc = _timed(f"linear_n1_bwd_masked[{m}x1x{k}]", lambda: (4 * (2 * m * k + m + 2 * k), 4 * m * k),
+                _lib.load().ctr_linear_n1_bwd_masked, x.data_ptr(), _ld(x), w.data_ptr(), gy.data_ptr(), _ld(gy), act_in,
+                gx.data_ptr(), _ld(gx), _lib.ptr(gw), _lib.ptr(gb), m, k, _lib.ptr(ws),
+                ws.numel() if ws is not None else 0, _lib.stream_ptr())
+    _lib.check(rc, "ctr_linear_n1_bwd_masked")
 
 
 def din_scatter_bwd(hist, vocab, dim, gh, attn, gpool, summed: bool, gtable) -> None:

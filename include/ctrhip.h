@@ -474,19 +474,31 @@ int ctr_ffm_fused_bwd(const float* x, int64_t ldx, int64_t batch, int dim, const
 /* DIN attention on the E-wide operand (model/din.py:39-44: W1 [h, h-t, t] = (Wa+Wb) h + (Wc-Wb) t, so the
  * first attention layer over all B*L positions only contracts the E columns of h; the per-sample term
  * u[b] = (Wc-Wb) t_b + b1 is added per GROUP of L consecutive rows):
- *   y[i, :] = act(x[i, :] W^T + bias + res[i / group, :])       (bias nullable; n <= 128) */
+ *   y[i, :] = act(x[i, :] W^T + bias + res[i / group, :])       (bias nullable; n <= 128)
+ * mask (nullable; n % 32 == 0, ldmask >= n/32 words): bit (j & 31) of mask[i*ldmask + j/32] = (y[i, j] > 0), the
+ * ReLU derivative for ctr_linear_dx_masked -- 1 bit instead of a 4-byte re-read of y per element in backward. */
 int ctr_linear_group_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias /*nullable*/,
                          const float* res, int64_t ldr, int group, float* y, int64_t ldy,
-                         int64_t m, int n, int k, int act, void* stream);
+                         uint32_t* mask /*nullable*/, int64_t ldmask, int64_t m, int n, int k, int act, void* stream);
 /* input gradient of a layer with the activation mask of the layer BELOW folded into the write-back, plus the
  * per-group column sums the grouped term above needs in backward:
  *   gx[i, :] = ((gy[i, :] * act'(y[i, :])) W) * act_in'(xin[i, :])      (xin = this layer's input = the
  *                                                                         previous layer's activation output)
  *   gsum[i / group, :] += gx[i, :]                                      (nullable; fp32 atomics; group >= 32)
- * k <= 128. */
+ * xmask (nullable; act_in = RELU, k % 32 == 0): the sign bits ctr_linear_group_fwd wrote for xin, used instead of
+ * reading xin.  k <= 128. */
 int ctr_linear_dx_masked(const float* w, int64_t ldw, const float* y, int64_t ldy, const float* gy, int64_t ldgy,
-                         int act, const float* xin, int64_t ldxin, int act_in, float* gx, int64_t ldgx,
+                         int act, const float* xin /*nullable with xmask*/, int64_t ldxin, int act_in,
+                         const uint32_t* xmask /*nullable*/, int64_t ldxmask, float* gx, int64_t ldgx,
                          float* gsum /*nullable*/, int64_t ldgsum, int group, int64_t m, int n, int k, void* stream);
+/* backward of the single-unit score layer y = x w^T + b (model/din.py:46, Linear(.., 1)) with the derivative of
+ * the activation that produced x folded in, so the gradient that leaves is already the pre-activation gradient
+ * of the layer below:
+ *   gx = (gy w) * act_in'(x)   (gx may be x itself -- x is dead after this in DIN's backward)
+ *   gw += gy^T x,  gb += sum gy        (either nullable; fixed-order partials through the workspace) */
+int ctr_linear_n1_bwd_masked(const float* x, int64_t ldx, const float* w, const float* gy, int64_t ldgy, int act_in,
+                             float* gx, int64_t ldgx, float* gw /*nullable*/, float* gb /*nullable*/, int64_t m, int k,
+                             float* workspace, int64_t workspace_floats, void* stream);
 
 /* ---- opt-in sparse mode of the embedding gradient / optimizer (replaces, for the rows a
  * batch touches, what `optim.Adam(model.parameters(), lr, weight_decay=1e-5)` does to whole tables:
