@@ -11,6 +11,7 @@
 // A sort is shared by every table addressed through the same id column (NeuralCF: the
 // MLP and GMF user tables use one sort of the user ids).
 #include "ctr_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -18,7 +19,7 @@ constexpr int kBlock = 256;
 constexpr int kMaxJobs = 8;
 constexpr int kMaxStreams = 16;
 constexpr int kMaxVocab = 8192;  // LDS histogram / one-workgroup scan
-constexpr int kRun = 16;         // sorted samples per lane group
+constexpr int kRunDefault = 8;   // sorted samples per lane group
 
 struct SortJob {
   const int64_t* idx;   // ID_I64 / PROD: ids, else NULL
@@ -31,6 +32,12 @@ struct SortJob {
   int32_t* total;       // [vocab] samples of the row
   int32_t* order;       // [batch] sample of every sorted position
   int32_t* keys;        // [batch] row of every sorted position
+  // companion column (a product field's other factor): its row per sorted position, written by the scatter pass so
+  // that the reduce pass needs no dependent id load per sample
+  const int64_t* cidx;
+  int64_t cidx_stride;
+  int64_t cvocab;
+  int32_t* ckeys;       // [batch] or NULL
 };
 struct SortJobs {
   int n;
@@ -44,6 +51,7 @@ struct Stream {
   const int64_t* pidx;
   int64_t pidx_stride;
   int64_t pvocab;
+  int use_ckeys;        // the partner rows are the job's companion column
 };
 struct Streams {
   int n;
@@ -61,6 +69,8 @@ __device__ __forceinline__ int load_row(const SortJob& j, uint32_t b) {
 // [w*chunk, (w+1)*chunk) of the batch in both passes:
 //   count:   LDS histogram of the slice -> hist[w][:]            (plain stores, no memset)
 //   colscan: base[w][v] = sum_{w'<w} hist[w'][v],  total[v] = sum_w hist[w][v]
+//            (folding this pass into the scatter workgroups was tried: each then sums nblk histograms itself, a
+//            chain of L2 round trips that took 34 us against 6 + 7 us for the two launches)
 //   scatter: LDS cursors start at (exclusive scan of total)[:] + base[w][:], ds_add_rtn hands
 //            out the positions
 __global__ void __launch_bounds__(kBlock) sort_count_kernel(const SortJobs J, uint32_t batch, uint32_t chunk) {
@@ -129,9 +139,12 @@ __global__ void __launch_bounds__(kBlock) sort_scatter_kernel(const SortJobs J, 
   const uint32_t lo = blockIdx.x * chunk, hi = lo + chunk < batch ? lo + chunk : batch;
   for (uint32_t b = lo + threadIdx.x; b < hi; b += kBlock) {
     const int r = load_row(j, b);
+    int64_t c = j.cidx ? ctr_ldg(j.cidx + (int64_t)b * j.cidx_stride) : 0;
+    if (c < 0 || c >= j.cvocab) c = 0;
     const int pos = atomicAdd(&s_cur[r], 1);
     j.order[pos] = (int)b;
     j.keys[pos] = r;
+    if (j.cidx) j.ckeys[pos] = (int)c;
   }
 }
 
@@ -155,6 +168,7 @@ __device__ __forceinline__ void flush_run(float* grad, int row, int width, int c
 // merges neighbours with equal rows before it touches memory, so a hot row with thousands
 // of samples costs one atomic per workgroup, not one per group (same-address fp32 atomics
 // serialise: 190 of them on the hottest ml-100k row were 20 us of this kernel's 35).
+template <int kRun>
 __global__ void __launch_bounds__(kBlock)
 seg_reduce_kernel(const SortJobs J, const Streams T, uint32_t batch, const float* __restrict__ gout, int64_t ldo) {
   __shared__ float s_sum[2 * kBlock * 4];  // [head|tail][group][lpr * 4]
@@ -173,13 +187,15 @@ seg_reduce_kernel(const SortJobs J, const Streams T, uint32_t batch, const float
   if (active) {
     // every load of the chunk is issued before the first use: keys/order, then the kRun
     // gradient rows (and the partner rows), then one serial pass over registers
-    int kk[kRun], bb[kRun];
+    int kk[kRun], bb[kRun], cc[kRun];
     float4 g[kRun];
+    const bool use_c = st.ptable && st.use_ckeys;
 #pragma unroll
     for (int u = 0; u < kRun; ++u) {
       const uint32_t p = u < n ? p0 + u : p0;
       kk[u] = j.keys[p];
       bb[u] = j.order[p];
+      cc[u] = use_c ? j.ckeys[p] : 0;
     }
 #pragma unroll
     for (int u = 0; u < kRun; ++u) {
@@ -191,8 +207,11 @@ seg_reduce_kernel(const SortJobs J, const Streams T, uint32_t batch, const float
       int64_t pr[kRun];
 #pragma unroll
       for (int u = 0; u < kRun; ++u) {
-        pr[u] = ctr_ldg(st.pidx + (int64_t)bb[u] * st.pidx_stride);
-        if (pr[u] < 0 || pr[u] >= st.pvocab) pr[u] = 0;
+        pr[u] = cc[u];
+        if (!use_c) {
+          pr[u] = ctr_ldg(st.pidx + (int64_t)bb[u] * st.pidx_stride);
+          if (pr[u] < 0 || pr[u] >= st.pvocab) pr[u] = 0;
+        }
       }
       if (live) {
 #pragma unroll
@@ -303,13 +322,14 @@ int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x,
       if (jb < 0) continue;
       if (jb == before) {
         SortJob& sj = J.j[jb];
+        sj = SortJob{};
         sj.idx = f.kind == CTR_FIELD_ID_I64 ? f.idx : nullptr;
         sj.idx_stride = f.idx_stride;
         sj.xcol = f.kind == CTR_FIELD_ID_F32 ? x + f.src_col : nullptr;
         sj.ldx = ldx;
         sj.vocab = (int32_t)f.vocab;
       }
-      T.s[T.n++] = Stream{jb, f.width, f.out_col, pow2_ceil(f.width / 4), f.grad, nullptr, nullptr, 0, 0};
+      T.s[T.n++] = Stream{jb, f.width, f.out_col, pow2_ceil(f.width / 4), f.grad, nullptr, nullptr, 0, 0, 0};
       handled[i] = 1;
     } else if (f.kind == CTR_FIELD_PROD_I64 && f.grad && f.grad2 && small(f.vocab) && small(f.vocab2) &&
                ctr_aligned16(f.grad) && ctr_aligned16(f.grad2) && ctr_aligned16(f.table) && ctr_aligned16(f.table2)) {
@@ -322,12 +342,32 @@ int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x,
         J.n = n0;  // do not keep a job nobody uses
         continue;
       }
-      if (j1 == n0) J.j[j1] = SortJob{f.idx, f.idx_stride, nullptr, 0, (int32_t)f.vocab, nullptr, nullptr, nullptr, nullptr, nullptr};
-      if (j2 == n1 && j2 != j1)
-        J.j[j2] = SortJob{f.idx2, f.idx_stride, nullptr, 0, (int32_t)f.vocab2, nullptr, nullptr, nullptr, nullptr, nullptr};
+      if (j1 == n0) {
+        J.j[j1] = SortJob{};
+        J.j[j1].idx = f.idx;
+        J.j[j1].idx_stride = f.idx_stride;
+        J.j[j1].vocab = (int32_t)f.vocab;
+      }
+      if (j2 == n1 && j2 != j1) {
+        J.j[j2] = SortJob{};
+        J.j[j2].idx = f.idx2;
+        J.j[j2].idx_stride = f.idx_stride;
+        J.j[j2].vocab = (int32_t)f.vocab2;
+      }
+      // the other factor's id column rides along as the job's companion (the first product field of a job wins)
+      auto companion = [&](int jb, const int64_t* cidx, int64_t cvocab) -> int {
+        SortJob& sj = J.j[jb];
+        if (!sj.cidx && cvocab < (1ll << 31)) {
+          sj.cidx = cidx;
+          sj.cidx_stride = f.idx_stride;
+          sj.cvocab = cvocab;
+        }
+        return sj.cidx == cidx && sj.cidx_stride == f.idx_stride && sj.cvocab == cvocab;
+      };
       const int lpr = pow2_ceil(f.width / 4);
-      T.s[T.n++] = Stream{j1, f.width, f.out_col, lpr, f.grad, f.table2, f.idx2, f.idx_stride, f.vocab2};
-      T.s[T.n++] = Stream{j2, f.width, f.out_col, lpr, f.grad2, f.table, f.idx, f.idx_stride, f.vocab};
+      const int c1 = companion(j1, f.idx2, f.vocab2), c2 = companion(j2, f.idx, f.vocab);
+      T.s[T.n++] = Stream{j1, f.width, f.out_col, lpr, f.grad, f.table2, f.idx2, f.idx_stride, f.vocab2, c1};
+      T.s[T.n++] = Stream{j2, f.width, f.out_col, lpr, f.grad2, f.table, f.idx, f.idx_stride, f.vocab, c2};
       handled[i] = 1;
     }
   }
@@ -337,11 +377,11 @@ int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x,
   if (nblk > 128) nblk = 128;
   const int64_t chunk = ctr_ceil_div(batch, nblk);
   nblk = (int)ctr_ceil_div(batch, chunk);
-  // int32 buffers at the end of the workspace: per job (2 * nblk + 1) * vocab + 2 * batch
+  // int32 buffers at the end of the workspace: per job (2 * nblk + 1) * vocab + 2 (3 with a companion column) * batch
   const int64_t b4 = (batch + 3) / 4 * 4;
   int64_t need = 0;
   for (int k = 0; k < J.n; ++k)
-    need += 2 * (((int64_t)nblk * J.j[k].vocab + 3) / 4 * 4) + (J.j[k].vocab + 3) / 4 * 4 + 2 * b4;
+    need += 2 * (((int64_t)nblk * J.j[k].vocab + 3) / 4 * 4) + (J.j[k].vocab + 3) / 4 * 4 + (J.j[k].cidx ? 3 : 2) * b4;
   if (need > workspace_floats) {
     for (int i = 0; i < nfields; ++i) handled[i] = 0;
     return CTR_OK;
@@ -360,6 +400,11 @@ int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x,
     at += b4;
     J.j[k].keys = at;
     at += b4;
+    J.j[k].ckeys = nullptr;
+    if (J.j[k].cidx) {
+      J.j[k].ckeys = at;
+      at += b4;
+    }
     maxv = J.j[k].vocab > maxv ? J.j[k].vocab : maxv;
   }
   *used_floats = need;
@@ -371,8 +416,20 @@ int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x,
   // grid.x sized for the narrowest stream's groups-per-workgroup; wider streams exit early
   int maxlpr = 1;
   for (int k = 0; k < T.n; ++k) maxlpr = T.s[k].lpr > maxlpr ? T.s[k].lpr : maxlpr;
-  const int64_t groups = ctr_ceil_div(batch, kRun);
+  // sorted samples per lane group: 8 (A/B on MI355X, NeuralCF step: 16 -> 181.3 us, 8 -> 177.2 us, 4 -> 177.6 us)
+  static const int run = [] {
+    const char* e = getenv("CTR_SEG_RUN");
+    const int v = e ? atoi(e) : kRunDefault;
+    return v == 4 || v == 16 ? v : 8;
+  }();
+  const int64_t groups = ctr_ceil_div(batch, run);
   const int gx = (int)ctr_ceil_div(groups, kBlock / maxlpr);
-  hipLaunchKernelGGL(seg_reduce_kernel, dim3(gx, T.n), dim3(kBlock), 0, st, J, T, (uint32_t)batch, gout, ldo);
+  const dim3 grid(gx, T.n);
+  if (run == 4)
+    hipLaunchKernelGGL(seg_reduce_kernel<4>, grid, dim3(kBlock), 0, st, J, T, (uint32_t)batch, gout, ldo);
+  else if (run == 16)
+    hipLaunchKernelGGL(seg_reduce_kernel<16>, grid, dim3(kBlock), 0, st, J, T, (uint32_t)batch, gout, ldo);
+  else
+    hipLaunchKernelGGL(seg_reduce_kernel<8>, grid, dim3(kBlock), 0, st, J, T, (uint32_t)batch, gout, ldo);
   return ctr_launch_status();
 }

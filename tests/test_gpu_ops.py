@@ -136,6 +136,56 @@ def test_embed_backward_small_tables_sorted_path(ops, batch, e):
                                    atol=1e-6 + 3e-6 * batch ** 0.5, msg=lambda m, k=k: f"grad of {k}: {m}")
 
 
+def test_embed_backward_sorted_path_at_the_largest_vocab(ops):
+    # 8192 rows: the largest vocabulary the counting sort takes (LDS histogram and cursors of 32 KB)
+    L = _lib()
+    g = torch.Generator().manual_seed(99)
+    batch, e, v = 70000, 8, 8192
+    t = torch.randn(v, e, generator=g)
+    idx = torch.randint(0, v, (batch,), generator=g)
+    idx[:3] = torch.tensor([0, v - 1, v - 1])
+    gout = torch.randn(batch, e, generator=g)
+    want = torch.zeros(v, e, dtype=torch.float64).index_add_(0, idx, gout.double())
+    dt = t.to(DEV)
+    grads = {id(dt): torch.zeros_like(dt)}
+    ops.embed_bwd([ops.FieldSpec(L.FIELD_ID_I64, e, 0, table=dt, idx=idx.to(DEV))], None, batch, gout.to(DEV), grads)
+    torch.testing.assert_close(grads[id(dt)].cpu(), want.float(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("batch,e", [(1000, 64), (77, 16), (5, 4)])
+def test_embed_forward_row_fields_from_separate_id_columns(ops, batch, e):
+    # NeuralCF's field set (model/neuralcf.py:35-38): two id fields and the product of two rows, ids in separate
+    # int64 vectors -- bit-exact copies / products, out-of-range ids of either factor flagged and read as row 0
+    L = _lib()
+    g = torch.Generator().manual_seed(batch)
+    v1, v2 = 40, 70
+    t1, t2 = torch.randn(v1, e, generator=g), torch.randn(v2, e, generator=g)
+    p1, p2 = torch.randn(v1, e, generator=g), torch.randn(v2, e, generator=g)
+    i1, i2 = torch.randint(0, v1, (batch,), generator=g), torch.randint(0, v2, (batch,), generator=g)
+    dev = {k: x.to(DEV) for k, x in dict(t1=t1, t2=t2, p1=p1, p2=p2, i1=i1, i2=i2).items()}
+
+    def run(a, b):
+        specs = [ops.FieldSpec(L.FIELD_ID_I64, e, 0, table=dev["t1"], idx=a),
+                 ops.FieldSpec(L.FIELD_ID_I64, e, e, table=dev["t2"], idx=b),
+                 ops.FieldSpec(L.FIELD_PROD_I64, e, 2 * e, table=dev["p1"], idx=a, table2=dev["p2"], idx2=b)]
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        out = torch.full((batch, 3 * e + 4), float("nan"), device=DEV)
+        ops.embed_fwd(specs, None, batch, out[:, :3 * e], flag)
+        return out.cpu(), int(flag.item())
+
+    out, flag = run(dev["i1"], dev["i2"])
+    assert flag == 0
+    assert torch.equal(out[:, :3 * e], torch.cat([t1[i1], t2[i2], p1[i1] * p2[i2]], 1))
+    assert torch.isnan(out[:, 3 * e:]).all()
+    b1, b2 = i1.clone(), i2.clone()
+    b1[0], b2[batch - 1] = v1, -3
+    out, flag = run(b1.to(DEV), b2.to(DEV))
+    assert flag == 1
+    c1, c2 = b1.clone(), b2.clone()
+    c1[0], c2[batch - 1] = 0, 0
+    assert torch.equal(out[:, :3 * e], torch.cat([t1[c1], t2[c2], p1[c1] * p2[c2]], 1))
+
+
 def test_embed_sequence_gather_is_bit_exact(ops):
     # K3: (B,L) history gathered column by column through idx_stride
     L = _lib()
