@@ -115,7 +115,7 @@ bool ctr_n1_supported(int k);
 // embed_sorted.hip: sorted segmented-reduce backward for small tables (see there)
 int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch,
                          const float* gout, int64_t ldo, float* workspace, int64_t workspace_floats,
-                         int64_t* used_floats, unsigned char* handled, hipStream_t st);
+                         int64_t* used_floats, unsigned char* handled, hipStream_t st, int phase = 0);
 // embed_bag.hip: bag-table gradients by register accumulation per output column (see there)
 int ctr_embed_bwd_bags(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch,
                        const float* gout, int64_t ldo, float* workspace, int64_t workspace_floats,

@@ -291,17 +291,26 @@ struct Key {
 // handled[i] is 1 for a field taken completely, 2 / 3 for a PROD field whose first / second
 // factor alone was taken (never happens today: both or none), 0 otherwise.  The sort buffers
 // are carved from the END of the workspace (embed.hip's bag partials use its start).
+//
+// phase 0: sort and reduce.  phase 1 (ctr_embed_bwd_presort): the sort alone, e.g. on a side stream while the
+// forward runs -- it only needs the ids.  phase 2 (ctr_embed_bwd_presorted): the reduce over buffers phase 1 left in
+// the same workspace.  In phases 1 and 2 the set of sort jobs and the workspace layout depend on the fields' kinds,
+// shapes and id columns only, never on the gradient pointers (phase 1 has none): both phases derive the same
+// layout, and a field without gradient simply gets no reduce stream.
 int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch,
                          const float* gout, int64_t ldo, float* workspace, int64_t workspace_floats,
-                         int64_t* used_floats, unsigned char* handled, hipStream_t st) {
+                         int64_t* used_floats, unsigned char* handled, hipStream_t st, int phase) {
   *used_floats = 0;
   for (int i = 0; i < nfields; ++i) handled[i] = 0;
-  if (!workspace || batch >= (1ll << 31) || !ctr_aligned16(gout) || ldo % 4 != 0) return CTR_OK;
+  const bool ghost = phase != 0;
+  if (!workspace || batch >= (1ll << 31) || ldo % 4 != 0) return CTR_OK;
+  if (phase != 1 && !ctr_aligned16(gout)) return CTR_OK;
   SortJobs J;
   Streams T;
   J.n = 0;
   T.n = 0;
   Key keys[kMaxJobs];
+  int vstreams = 0;  // reduce streams the fields would get with every gradient present (limits the job set)
   auto job_of = [&](const void* base, int64_t stride, int64_t vocab) -> int {
     for (int k = 0; k < J.n; ++k)
       if (keys[k].base == base && keys[k].stride == stride && keys[k].vocab == vocab) return k;
@@ -314,8 +323,9 @@ int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x,
     const ctr_field_t& f = fields[i];
     const bool shape_ok = f.width % 4 == 0 && f.out_col % 4 == 0 && f.width <= 256;
     if (!shape_ok) continue;
-    if ((f.kind == CTR_FIELD_ID_I64 || f.kind == CTR_FIELD_ID_F32) && f.grad && small(f.vocab) && ctr_aligned16(f.grad)) {
-      if (T.n + 1 > kMaxStreams) continue;
+    const bool g1 = f.grad && ctr_aligned16(f.grad), g2 = f.grad2 && ctr_aligned16(f.grad2);
+    if ((f.kind == CTR_FIELD_ID_I64 || f.kind == CTR_FIELD_ID_F32) && (ghost || g1) && small(f.vocab)) {
+      if (vstreams + 1 > kMaxStreams) continue;
       const int before = J.n;
       const int jb = f.kind == CTR_FIELD_ID_I64 ? job_of(f.idx, f.idx_stride, f.vocab)
                                                 : job_of(x + f.src_col, ldx, f.vocab);
@@ -329,11 +339,14 @@ int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x,
         sj.ldx = ldx;
         sj.vocab = (int32_t)f.vocab;
       }
-      T.s[T.n++] = Stream{jb, f.width, f.out_col, pow2_ceil(f.width / 4), f.grad, nullptr, nullptr, 0, 0, 0};
-      handled[i] = 1;
-    } else if (f.kind == CTR_FIELD_PROD_I64 && f.grad && f.grad2 && small(f.vocab) && small(f.vocab2) &&
-               ctr_aligned16(f.grad) && ctr_aligned16(f.grad2) && ctr_aligned16(f.table) && ctr_aligned16(f.table2)) {
-      if (T.n + 2 > kMaxStreams) continue;
+      vstreams += 1;
+      if (g1) {
+        T.s[T.n++] = Stream{jb, f.width, f.out_col, pow2_ceil(f.width / 4), f.grad, nullptr, nullptr, 0, 0, 0};
+        handled[i] = 1;
+      }
+    } else if (f.kind == CTR_FIELD_PROD_I64 && (ghost || (g1 && g2)) && small(f.vocab) && small(f.vocab2) &&
+               ctr_aligned16(f.table) && ctr_aligned16(f.table2)) {
+      if (vstreams + 2 > kMaxStreams) continue;
       const int n0 = J.n;
       const int j1 = job_of(f.idx, f.idx_stride, f.vocab);
       const int n1 = J.n;
@@ -366,12 +379,18 @@ int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x,
       };
       const int lpr = pow2_ceil(f.width / 4);
       const int c1 = companion(j1, f.idx2, f.vocab2), c2 = companion(j2, f.idx, f.vocab);
-      T.s[T.n++] = Stream{j1, f.width, f.out_col, lpr, f.grad, f.table2, f.idx2, f.idx_stride, f.vocab2, c1};
-      T.s[T.n++] = Stream{j2, f.width, f.out_col, lpr, f.grad2, f.table, f.idx, f.idx_stride, f.vocab, c2};
-      handled[i] = 1;
+      vstreams += 2;
+      if (g1 && g2) {
+        T.s[T.n++] = Stream{j1, f.width, f.out_col, lpr, f.grad, f.table2, f.idx2, f.idx_stride, f.vocab2, c1};
+        T.s[T.n++] = Stream{j2, f.width, f.out_col, lpr, f.grad2, f.table, f.idx, f.idx_stride, f.vocab, c2};
+        handled[i] = 1;
+      }
     }
   }
-  if (T.n == 0) return CTR_OK;
+  if (J.n == 0 || (phase != 1 && T.n == 0)) {
+    for (int i = 0; i < nfields; ++i) handled[i] = 0;
+    return CTR_OK;
+  }
   // workgroups of the two sort passes: contiguous slices of >= 1024 samples
   int nblk = (int)ctr_ceil_div(batch, 1024);
   if (nblk > 128) nblk = 128;
@@ -408,11 +427,14 @@ int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x,
     maxv = J.j[k].vocab > maxv ? J.j[k].vocab : maxv;
   }
   *used_floats = need;
+  if (phase != 2) {
   hipLaunchKernelGGL(sort_count_kernel, dim3(nblk, J.n), dim3(kBlock), sizeof(int) * maxv, st, J, (uint32_t)batch,
                      (uint32_t)chunk);
   hipLaunchKernelGGL(sort_colscan_kernel, dim3((unsigned)ctr_ceil_div(maxv, kBlock), J.n), dim3(kBlock), 0, st, J, nblk);
   hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblk, J.n), dim3(kBlock), sizeof(int) * maxv, st, J, (uint32_t)batch,
                      (uint32_t)chunk);
+  }
+  if (phase == 1) return ctr_launch_status();
   // grid.x sized for the narrowest stream's groups-per-workgroup; wider streams exit early
   int maxlpr = 1;
   for (int k = 0; k < T.n; ++k) maxlpr = T.s[k].lpr > maxlpr ? T.s[k].lpr : maxlpr;

@@ -1,6 +1,8 @@
 """NeuralCF -- counterpart of the reference's model/neuralcf.py:7-72."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -10,6 +12,12 @@ from .. import ops
 from ..ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, FieldSpec, Layer
 from .._lib import FIELD_ID_I64, FIELD_PROD_I64
 from ._base import CtrModule
+
+# Opt-in (CTR_NCF_OVERLAP_SORT=1): start the id-only half of the embedding backward on a side stream during the
+# forward.  Measured on MI355X with the step captured in a hipGraph: 184.7 us with the parallel branch against
+# 178.1 us without -- the cross-stream edges of the graph cost more than the 19 us of sort they take off the
+# critical path -- so the default is the single-stream order.
+OVERLAP_SORT = os.environ.get("CTR_NCF_OVERLAP_SORT", "0") == "1"
 
 
 class _NeuralCFFunction(torch.autograd.Function):
@@ -39,6 +47,12 @@ class _NeuralCFFunction(torch.autograd.Function):
         kh = proj_w.shape[1]  # width of h
         buf = torch.empty((batch, l0 + mf + (kh if n_hidden else 0)), dtype=torch.float32, device=gmf_u.device)
         specs = _specs(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i)
+        # opt-in (see OVERLAP_SORT): the counting sort of the embedding backward on a side stream, joined in backward
+        sort_ws = side = None
+        if OVERLAP_SORT and any(ctx.needs_input_grad[4:8]):
+            sort_ws = ops.new_scratch(buf.device)
+            with ops.SideStream(buf.device) as side:
+                ops.embed_bwd_presort(specs, None, batch, buf.stride(0), sort_ws)
         ops.embed_fwd(specs, None, batch, buf, err_flag)
         wfold, cfold = ops.fold_head_fwd(head_w, mf, proj_w, proj_b, head_b)
         if n_hidden:
@@ -53,6 +67,7 @@ class _NeuralCFFunction(torch.autograd.Function):
             wf = torch.cat([wfold[:, mf:], wfold[:, :mf]], dim=1)
             prob = ops.linear_fwd(buf, wf, cfold, ACT_SIGMOID)
         ctx.n_hidden = n_hidden
+        ctx.sort_ws, ctx.sort_side = sort_ws, side
         ctx.save_for_backward(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i, buf, prob, wfold, *acts[1:-1], *dense)
         return prob
 
@@ -95,7 +110,10 @@ class _NeuralCFFunction(torch.autograd.Function):
         g_head_w, g_head_b = zeros[id(head_w)], zeros[id(head_b)]
         ops.fold_head_bwd(head_w, mf, proj_w, proj_b, gwfold, gcfold, g_head_w, g_proj_w, g_proj_b, g_head_b)
         tgrads = zeros
-        ops.embed_bwd(_specs(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i), None, batch, gbuf, tgrads)
+        if ctx.sort_side is not None:
+            ctx.sort_side.join()  # the sort the forward started
+        ops.embed_bwd(_specs(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i), None, batch, gbuf, tgrads,
+                      presorted=ctx.sort_ws)
         out = [None, None, None, None] + [tgrads[id(t)] for t in tables]
         for gw, gb in layer_grads:
             out += [gw, gb]
