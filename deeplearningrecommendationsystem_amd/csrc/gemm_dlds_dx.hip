@@ -12,6 +12,7 @@
 // positions that are then duplicates or past n; along W's columns (k % 4 != 0) the reader adds the
 // shift to its column index.
 #include "ctr_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -333,7 +334,10 @@ static int launch_dx(const float* w, int64_t ldw, const float* y, int64_t ldy, c
   const int nt = k <= 32 ? 1 : (k <= 64 ? 2 : 4);
   const int64_t mtiles = ctr_ceil_div(m, kBM);
   const int64_t ny = ctr_ceil_div(k, 32 * nt);
-  int64_t gx_ = 256 * 2 / ny;  // rounded down: a workgroup beyond the resident 2 per CU would start a second round
+  // rounded down: a workgroup beyond the resident ones would start a second round.  Two per CU with a Y tile in the
+  // ring (72 KB of LDS); without one (48 KB, <= 144 registers) three fit
+  static const int wgs_plain = [] { const char* e = getenv("CTR_DX_WGS"); return e && e[0] == '2' ? 2 : 3; }();
+  int64_t gx_ = 256 * (act == CTR_ACT_NONE ? wgs_plain : 2) / ny;
   if (gx_ > mtiles) gx_ = mtiles;
   if (gx_ < 1) gx_ = 1;
   CTR_REQUIRE(ny <= 65535, CTR_ELIMIT);
