@@ -934,16 +934,8 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
           tile_load4<4, S::kFixed>(xt, xs, src, ld_in, row0, m, L.k, L.div_k4, lane);
         }
         __builtin_amdgcn_wave_barrier();
-        // bias gradient: lane j sums column j of gZ over the 32 rows
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-          const int j = lane + 64 * half;
-          if (j < L.n) {
-            float t = 0.0f;
-            for (int rr = 0; rr < 32; ++rr) t += gt[rr * gs + j];
-            s_db[dboff + j] += t;
-          }
-        }
+        // (bias gradient: taken from the gZ fragments of the dW products below -- a column's 32 values are the 16
+        // of each half-wave's fragment -- instead of 32 more LDS reads per column)
         CTR_STAMP();
         // dW_l[n][k] += sum_rows gZ[row][n] X[row][k]: contraction = the 32 rows, 16 steps.
         // The accumulator index must be a compile-time constant (a run-time index would
@@ -958,36 +950,61 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
             const bool okA = relA >= 0 && relA < nrt * nkt, okB = relB >= 0 && relB < nrt * nkt;
             if (okA || okB) {
               float faA[16], fbA[16], faB[16], fbB[16];
-              {
-                const int it = okA ? relA / nkt : 0, jt = okA ? relA - it * nkt : 0;
-                const int ncol = 32 * it + r, kcol = 32 * jt + r;
-                // columns past n / k read their neighbours in LDS and land in dW elements
-                // that the flush drops; only a slot of another layer must add nothing
-                if (okA) {
-                  read_ks<16>(gt, gs, ncol, 0, h, faA);
-                  read_ks<16>(xt, xs, kcol, 0, h, fbA);
-                } else {
+              const int itA = okA ? relA / nkt : 0, jtA = okA ? relA - itA * nkt : 0;
+              const int itB = okB ? relB / nkt : 0, jtB = okB ? relB - itB * nkt : 0;
+              // columns past n / k read their neighbours in LDS and land in dW elements
+              // that the flush drops; only a slot of another layer must add nothing
+              if (okA) {
+                read_ks<16>(gt, gs, 32 * itA + r, 0, h, faA);
+                read_ks<16>(xt, xs, 32 * jtA + r, 0, h, fbA);
+              } else {
 #pragma unroll
-                  for (int t = 0; t < 16; ++t) faA[t] = fbA[t] = 0.0f;
+                for (int t = 0; t < 16; ++t) faA[t] = fbA[t] = 0.0f;
+              }
+              if (okB) {
+                if (okA && itB == itA) {   // the pair shares its row of tiles: one gZ fragment
+#pragma unroll
+                  for (int t = 0; t < 16; ++t) faB[t] = faA[t];
+                } else {
+                  read_ks<16>(gt, gs, 32 * itB + r, 0, h, faB);
+                }
+                read_ks<16>(xt, xs, 32 * jtB + r, 0, h, fbB);
+              } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) faB[t] = fbB[t] = 0.0f;
+              }
+              // bias gradient of the columns 32*it .. +31, once per row of tiles (at its first tile)
+              if ((okA && jtA == 0) || (okB && jtB == 0)) {
+                const bool fromA = okA && jtA == 0;
+                const int itD = fromA ? itA : itB;
+                float t = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) t += fromA ? faA[q] : faB[q];
+                t += __shfl_xor(t, 32, 64);
+                if (h == 0 && 32 * itD + r < L.n) s_db[dboff + 32 * itD + r] += t;
+                if (okA && okB && jtA == 0 && jtB == 0) {   // one-tile-wide layer: both slots start a row of tiles
+                  float u = 0.0f;
+#pragma unroll
+                  for (int q = 0; q < 16; ++q) u += faB[q];
+                  u += __shfl_xor(u, 32, 64);
+                  if (h == 0 && 32 * itB + r < L.n) s_db[dboff + 32 * itB + r] += u;
                 }
               }
-              {
-                const int it = okB ? relB / nkt : 0, jt = okB ? relB - it * nkt : 0;
-                const int ncol = 32 * it + r, kcol = 32 * jt + r;
-                // columns past n / k read their neighbours in LDS and land in dW elements
-                // that the flush drops; only a slot of another layer must add nothing
-                if (okB) {
-                  read_ks<16>(gt, gs, ncol, 0, h, faB);
-                  read_ks<16>(xt, xs, kcol, 0, h, fbB);
-                } else {
+              // a slot of another layer gets no MFMA at all (fixed shapes: okA / okB are constants; multiplying its
+              // zero fragments cost the pinned tower 32 of 408 matrix instructions per tile)
+              if (okA && okB) {
 #pragma unroll
-                  for (int t = 0; t < 16; ++t) faB[t] = fbB[t] = 0.0f;
+                for (int t = 0; t < 16; ++t) {
+                  dw[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(faA[t], fbA[t], dw[s2], 0, 0, 0);
+                  dw[s2 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(faB[t], fbB[t], dw[s2 + 1], 0, 0, 0);
                 }
-              }
+              } else if (okA) {
 #pragma unroll
-              for (int t = 0; t < 16; ++t) {
-                dw[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(faA[t], fbA[t], dw[s2], 0, 0, 0);
-                dw[s2 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(faB[t], fbB[t], dw[s2 + 1], 0, 0, 0);
+                for (int t = 0; t < 16; ++t) dw[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(faA[t], fbA[t], dw[s2], 0, 0, 0);
+              } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                  dw[s2 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(faB[t], fbB[t], dw[s2 + 1], 0, 0, 0);
               }
             }
           }
