@@ -36,6 +36,9 @@ struct DxArgs {
   float* gsum; int64_t ldgsum; int group;
   // instead of xin: the sign bits ctr_linear_group_fwd wrote (bit (c & 31) of xmask[i*ldxmask + c/32]); gx *= bit
   const uint32_t* xmask; int64_t ldxmask;
+  // EPI == 2 (ctr_linear_dx_scatter): gx is not stored; row i (+ attn[i] * gpool[i / group, :]) is ADDED to row
+  // idx[i] of a (vocab, k) table gradient -- DIN's history gradient without the (B*L, E) intermediate
+  const int64_t* sc_idx; const float* sc_attn; const float* sc_gpool; int64_t sc_ldgp; float* sc_table; int64_t sc_vocab;
 };
 
 template <int N>
@@ -97,7 +100,7 @@ __device__ __forceinline__ void fetch_w(float* stage, const float* __restrict__ 
   }
 }
 
-template <int NT, int ACT, bool EPI = false>
+template <int NT, int ACT, int EPI = 0>   // EPI: 0 plain, 1 masked write-back + group sums, 2 scatter-add by row ids
 __global__ void __launch_bounds__(kThreads, 2)
 gemm_dx_dlds_kernel(const DxArgs a) {
   constexpr int BW = 32 * NT;
@@ -118,6 +121,11 @@ gemm_dx_dlds_kernel(const DxArgs a) {
 
   constexpr int CH = 4 / NT;
   floatx16 acc[NT][CH];
+  // EPI 2: what this lane's columns add to the padding row (id 0 is a quarter of DIN's history positions: one
+  // atomic per sample there is a chain of same-address adds), flushed once at the end
+  float padacc[NT];
+#pragma unroll
+  for (int nb = 0; nb < NT; ++nb) padacc[nb] = 0.0f;
 
   auto advance = [&](int64_t& t, int& ks) {
     if (++ks == nk) {
@@ -156,8 +164,31 @@ gemm_dx_dlds_kernel(const DxArgs a) {
         for (int e = 0; e < 16; ++e) acc[nb][c][e] = 0.0f;
     // sign-bit words of this wave's 32 rows (lane r: row r, one word per column tile), requested in front of the
     // contraction: a load issued in the epilogue is waited for together with the stores of the tiles before it
+    int idrow = -1;
+    float attnrow = 0.0f, sg0[NT], sg1[NT];
+    int64_t sc_edge = 0;
+    if constexpr (EPI == 2) {
+      // lane r: id and attention weight of row r of the wave's 32; per column tile the pooled gradient of the (at
+      // most two, group >= 32) samples those rows belong to -- all requested in front of the contraction
+      const int64_t first = i0 + 32 * wave;
+      const int64_t row = first + r;
+      if (row < a.m) {
+        const int64_t t = ctr_ldg(a.sc_idx + row);
+        idrow = (t >= 0 && t < a.sc_vocab) ? (int)t : -1;
+        attnrow = ctr_ldg(a.sc_attn + row);
+      }
+      const int64_t b0 = (first < a.m ? first : a.m - 1) / a.group;
+      sc_edge = (b0 + 1) * (int64_t)a.group;
+      const int64_t b1 = sc_edge < a.m ? b0 + 1 : b0;
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb) {
+        const int col = c0 + 32 * nb + r;
+        sg0[nb] = ctr_ldg(a.sc_gpool + b0 * a.sc_ldgp + col);
+        sg1[nb] = ctr_ldg(a.sc_gpool + b1 * a.sc_ldgp + col);
+      }
+    }
     uint32_t mrow[NT];
-    if constexpr (EPI) {
+    if constexpr (EPI == 1) {
       if (a.xmask) {
         const int64_t row = i0 + 32 * wave + r;
 #pragma unroll
@@ -209,7 +240,30 @@ gemm_dx_dlds_kernel(const DxArgs a) {
       stage = stage + 1 == kStages ? 0 : stage + 1;
     }
     // C/D map: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    if constexpr (EPI) {
+    if constexpr (EPI == 2) {
+      const int64_t first = i0 + 32 * wave;
+#pragma unroll
+      for (int nb = 0; nb < NT; ++nb) {
+        const int col = c0 + 32 * nb + r;   // k % 32 == 0 (host): every column exists
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          float v = acc[nb][0][e];
+#pragma unroll
+          for (int c = 1; c < CH; ++c) v += acc[nb][c][e];
+          const int rho = (e & 3) + 8 * (e >> 2);
+          const int id0 = __builtin_amdgcn_readlane(idrow, rho), id1 = __builtin_amdgcn_readlane(idrow, rho + 4);
+          const float at0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, attnrow), rho));
+          const float at1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, attnrow), rho + 4));
+          const int id = h ? id1 : id0;
+          const int64_t i = first + rho + 4 * h;
+          v = fmaf(h ? at1 : at0, i < sc_edge ? sg0[nb] : sg1[nb], v);
+          if (id > 0) ctr_atomic_add_global(a.sc_table + (int64_t)id * a.k + col, v);
+          else if (id == 0) padacc[nb] += v;
+        }
+      }
+      continue;
+    }
+    if constexpr (EPI == 1) {
       // mask by act'(xin) and per-group column sums.  The mask values of TWO column tiles are requested before
       // the first is used: every wait on an epilogue load also drains the ring's loads of the next tile, so one
       // dependent group of 16 loads per column tile stalled the pipeline four times per row tile (+500 us on
@@ -311,6 +365,24 @@ gemm_dx_dlds_kernel(const DxArgs a) {
       }
     }
   }
+  if constexpr (EPI == 2) {
+    // the workgroup's share of the padding row: half-waves fold by shuffle, waves through LDS (the ring is idle:
+    // every wave has passed its last contraction step), one atomic per column
+    __shared__ float s_pad[kThreads / 64][32 * NT];
+    const int r = lane0 & 31, h = lane0 >> 5;
+#pragma unroll
+    for (int nb = 0; nb < NT; ++nb) {
+      float t = padacc[nb];
+      t += __shfl_xor(t, 32, 64);
+      if (h == 0) s_pad[wave][32 * nb + r] = t;
+    }
+    __syncthreads();
+    for (int cidx = threadIdx.x; cidx < 32 * NT; cidx += kThreads) {
+      float t = 0.0f;
+      for (int wv = 0; wv < kThreads / 64; ++wv) t += s_pad[wv][cidx];
+      if (t != 0.0f) ctr_atomic_add_global(a.sc_table + c0 + cidx, t);
+    }
+  }
 }
 
 }  // namespace
@@ -326,6 +398,9 @@ struct DxEpilogue {
   const float* xin = nullptr; int64_t ldxin = 0; int act_in = CTR_ACT_NONE;
   float* gsum = nullptr; int64_t ldgsum = 0; int group = 1;
   const uint32_t* xmask = nullptr; int64_t ldxmask = 0;
+  int mode = 1;   // 1: masked write-back + group sums, 2: scatter-add by row ids
+  const int64_t* sc_idx = nullptr; const float* sc_attn = nullptr; const float* sc_gpool = nullptr; int64_t sc_ldgp = 0;
+  float* sc_table = nullptr; int64_t sc_vocab = 0;
 };
 
 static int launch_dx(const float* w, int64_t ldw, const float* y, int64_t ldy, const float* gy, int64_t ldgy, float* gx,
@@ -342,11 +417,13 @@ static int launch_dx(const float* w, int64_t ldw, const float* y, int64_t ldy, c
   if (gx_ < 1) gx_ = 1;
   CTR_REQUIRE(ny <= 65535, CTR_ELIMIT);
   const DxArgs a{gy, ldgy, act == CTR_ACT_NONE ? nullptr : y, ldy, w, ldw, gx, ldgx, m, n, k, accumulate,
-                 ep.xin, ep.ldxin, ep.act_in, ep.gsum, ep.ldgsum, ep.group, ep.xmask, ep.ldxmask};
+                 ep.xin, ep.ldxin, ep.act_in, ep.gsum, ep.ldgsum, ep.group, ep.xmask, ep.ldxmask,
+                 ep.sc_idx, ep.sc_attn, ep.sc_gpool, ep.sc_ldgp, ep.sc_table, ep.sc_vocab};
   const dim3 grid((unsigned)gx_, (unsigned)ny);
 #define CTR_DX(NT_, ACT_)                                                                                  \
   do {                                                                                                     \
-    if (ep.on) hipLaunchKernelGGL((gemm_dx_dlds_kernel<NT_, ACT_, true>), grid, dim3(kThreads), 0, st, a); \
+    if (ep.on && ep.mode == 2) hipLaunchKernelGGL((gemm_dx_dlds_kernel<NT_, CTR_ACT_NONE, 2>), grid, dim3(kThreads), 0, st, a); \
+    else if (ep.on) hipLaunchKernelGGL((gemm_dx_dlds_kernel<NT_, ACT_, 1>), grid, dim3(kThreads), 0, st, a); \
     else hipLaunchKernelGGL((gemm_dx_dlds_kernel<NT_, ACT_>), grid, dim3(kThreads), 0, st, a);             \
   } while (0)
 #define CTR_DX_ACT(NT_)                                      \
@@ -403,4 +480,27 @@ extern "C" int ctr_linear_dx_masked(const float* w, int64_t ldw, const float* y,
   ep.ldgsum = ldgsum;
   ep.group = gsum ? group : 1;
   return launch_dx(w, ldw, y, ldy, gy, ldgy, gx, ldgx, 0, m, n, k, act, (hipStream_t)stream, ep);
+}
+
+// C ABI (include/ctrhip.h): table[idx[i], :] += gY[i, :] W + attn[i] * gpool[i / group, :]   (gX itself is not stored)
+extern "C" int ctr_linear_dx_scatter(const float* w, int64_t ldw, const float* gy, int64_t ldgy, const int64_t* idx,
+                                     const float* attn, const float* gpool, int64_t ldgp, int group, float* table,
+                                     int64_t vocab, int64_t m, int n, int k, void* stream) {
+  CTR_REQUIRE(m >= 0 && n >= 1 && k >= 1, CTR_EINVAL);
+  if (m == 0) return CTR_OK;
+  CTR_REQUIRE(w && gy && idx && attn && gpool && table && ldw >= k && ldgy >= n && ldgp >= k, CTR_EINVAL);
+  CTR_REQUIRE(group >= 32 && vocab >= 1, CTR_EINVAL);  // a wave's 32 rows span at most two groups
+  CTR_REQUIRE(k % 32 == 0 && k <= 128 && vocab < (1ll << 31) && m < (1ll << 40), CTR_ELIMIT);
+  CTR_REQUIRE(ctr_gemm_dlds_dx_ok(w, ldw, nullptr, 0, gy, ldgy, m, n, k, CTR_ACT_NONE), CTR_ELIMIT);
+  DxEpilogue ep;
+  ep.on = true;
+  ep.mode = 2;
+  ep.group = group;
+  ep.sc_idx = idx;
+  ep.sc_attn = attn;
+  ep.sc_gpool = gpool;
+  ep.sc_ldgp = ldgp;
+  ep.sc_table = table;
+  ep.sc_vocab = vocab;
+  return launch_dx(w, ldw, nullptr, 0, gy, ldgy, /*gx (unused)*/ table, k, 0, m, n, k, CTR_ACT_NONE, (hipStream_t)stream, ep);
 }

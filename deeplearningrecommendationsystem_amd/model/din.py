@@ -1,6 +1,8 @@
 """DIN -- counterpart of the reference's model/din.py:9-66."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -9,6 +11,10 @@ from torch.nn.init import xavier_normal_
 from .. import ops
 from ..ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, Layer
 from ._base import CtrModule, _ModelFunction
+
+# the history gradient of the E-wide attention leaves the first layer's dX GEMM as atomics on the table gradient
+# (ctr_linear_dx_scatter); CTR_DIN_FUSED_SCATTER=0 keeps the two-pass form (dX to memory, seq_scatter) for A/B
+FUSED_SCATTER = os.environ.get("CTR_DIN_FUSED_SCATTER", "1") != "0"
 
 
 def attention_layers(p):
@@ -215,8 +221,16 @@ class DIN(SequenceModel):
         ops.linear_dx_masked(att[1].weight, None, gz2, ACT_NONE, z1, ACT_RELU, gz1, gu, length, sign_bits=bits)
         # layer 1 on the E-wide operand (gz1 already carries relu'(z1))
         gwf = torch.zeros_like(wf)
-        ghrows = torch.empty_like(hrows)
-        ops.linear_bwd(hrows, wf[0], None, gz1, ACT_NONE, ghrows, gwf[0], zeros[id(b1)])
+        gtable = zeros[id(table)]
+        fused_scatter = FUSED_SCATTER and dim % 32 == 0 and dim <= 128 and length >= 32 and table.shape[0] < 2 ** 31
+        if fused_scatter:
+            # dWh alone, then the input gradient added straight to the history rows of the table gradient (with
+            # the pooling's share): the (B*L, E) gradient and its scatter pass never exist
+            ops.linear_bwd(hrows, wf[0], None, gz1, ACT_NONE, None, gwf[0], zeros[id(b1)])
+            ops.linear_dx_scatter(wf[0], gz1, hist.reshape(-1), attn.reshape(-1), gfcin[:, :dim], length, gtable)
+        else:
+            ghrows = torch.empty_like(hrows)
+            ops.linear_bwd(hrows, wf[0], None, gz1, ACT_NONE, ghrows, gwf[0], zeros[id(b1)])
         # u = t Wu^T + b1: dWu = gu^T t, and the target's gradient gains gu Wu on top of the fc input's share
         gt = gfcin[:, dim:]
         ops.linear_bwd(fcin[:, dim:], wf[1], None, gu, ACT_NONE, gt, gwf[1], None, accumulate_gx=True)
@@ -224,8 +238,8 @@ class DIN(SequenceModel):
         gw1[:, :dim].copy_(gwf[0])
         torch.sub(gwf[0], gwf[1], out=gw1[:, dim:2 * dim])
         gw1[:, 2 * dim:].copy_(gwf[1])
-        gtable = zeros[id(table)]
-        ops.din_scatter_bwd(hist, table.shape[0], dim, ghrows, attn, gfcin[:, :dim], True, gtable)
+        if not fused_scatter:
+            ops.din_scatter_bwd(hist, table.shape[0], dim, ghrows, attn, gfcin[:, :dim], True, gtable)
         ops.embed_bwd([ops.FieldSpec(_lib_field_id(), dim, dim, table=table, idx=target)], None, batch, gfcin,
                       {id(table): gtable})
         grads = [gtable]

@@ -885,6 +885,25 @@ def linear_dx_masked(w, y, gy, act: int, xin, act_in: int, gx, gsum=None, group:
     _lib.check(rc, "ctr_linear_dx_masked")
 
 
+def linear_dx_scatter(w, gy, idx, attn, gpool, group: int, gtable) -> None:
+    """gtable[idx[i]] += gy[i] @ w + attn[i] * gpool[i // group]: the input gradient of a layer whose input rows were
+    gathered from ``gtable``'s table, added where the rows came from without storing the (m, k) gradient (DIN)"""
+    w, gy, gpool, gtable = _mat(w, "w"), _mat(gy, "gy"), _mat(gpool, "gpool"), _mat(gtable, "gtable")
+    _lib.require_device(idx, attn)
+    m, n = gy.shape
+    k = w.shape[1]
+    if idx.dtype != torch.int64 or not idx.is_contiguous() or idx.numel() != m or attn.numel() != m or \
+            not attn.is_contiguous() or attn.dtype != torch.float32:
+        raise ValueError("linear_dx_scatter: idx (int64) and attn (float32) must be contiguous with one entry per row")
+    if gtable.shape[1] != k or not gtable.is_contiguous():
+        raise ValueError("linear_dx_scatter: gtable must be a contiguous (vocab, k) tensor")
+    rc = _timed(f"linear_dx_scatter[{m}x{n}x{k}]", lambda: (4 * (m * n + n * k + 3 * m + 3 * m * k), 2 * m * n * k),
+                _lib.load().ctr_linear_dx_scatter, w.data_ptr(), _ld(w), gy.data_ptr(), _ld(gy), idx.data_ptr(),
+                attn.data_ptr(), gpool.data_ptr(), _ld(gpool), group, gtable.data_ptr(), gtable.shape[0], m, n, k,
+                _lib.stream_ptr())
+    _lib.check(rc, "ctr_linear_dx_scatter")
+
+
 def linear_n1_bwd_masked(x, w, gy, act_in: int, gx, gw=None, gb=None) -> None:
     """backward of the single-unit layer y = x @ w.T + b whose input x is the previous layer's activation output:
     gx = (gy @ w) * act_in'(x) (``gx`` may be ``x`` itself), gw += gy.T @ x, gb += gy.sum()"""

@@ -503,6 +503,15 @@ int ctr_linear_dx_masked(const float* w, int64_t ldw, const float* y, int64_t ld
                          int act, const float* xin /*nullable with xmask*/, int64_t ldxin, int act_in,
                          const uint32_t* xmask /*nullable*/, int64_t ldxmask, float* gx, int64_t ldgx,
                          float* gsum /*nullable*/, int64_t ldgsum, int group, int64_t m, int n, int k, void* stream);
+/* input gradient of DIN's first attention layer on the E-wide operand, scattered straight into the item table's
+ * gradient (model/din.py:35-44 backward: the history rows h = table[hist] receive gX plus the pooling's share):
+ *   table[idx[i], :] += gy[i, :] W + attn[i] * gpool[i / group, :]          i < m;  W is (n, k), table (vocab, k)
+ * The (m, k) gradient itself is never stored.  fp32 atomics; rows with idx 0 (the padding id, a quarter of DIN's
+ * positions) are summed per workgroup first; ids outside [0, vocab) add nothing.  k % 32 == 0, k <= 128,
+ * group >= 32, vocab < 2^31. */
+int ctr_linear_dx_scatter(const float* w, int64_t ldw, const float* gy, int64_t ldgy, const int64_t* idx,
+                          const float* attn, const float* gpool, int64_t ldgp, int group, float* table,
+                          int64_t vocab, int64_t m, int n, int k, void* stream);
 /* backward of the single-unit score layer y = x w^T + b (model/din.py:46, Linear(.., 1)) with the derivative of
  * the activation that produced x folded in, so the gradient that leaves is already the pre-activation gradient
  * of the layer below:

@@ -928,6 +928,30 @@ def test_linear_dx_masked_and_group_sums(ops, m, n, k, group):
     torch.testing.assert_close(gx2.cpu(), (gy.double() @ w.double()).float(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("batch,length,n,k,vocab", [(40, 100, 128, 64, 500), (7, 33, 64, 32, 50), (3, 130, 16, 128, 1000)])
+def test_linear_dx_scatter_adds_the_input_gradient_where_the_rows_came_from(ops, batch, length, n, k, vocab):
+    # DIN's history gradient (model/din.py:35-44 backward): table[hist[i]] += gy[i] W + attn[i] * gpool[i // L];
+    # a quarter of the positions are the padding id 0 (summed per workgroup), a few ids are out of range (dropped)
+    g = torch.Generator().manual_seed(batch * length + k)
+    m = batch * length
+    w = torch.randn(n, k, generator=g) / n ** 0.5
+    gy = torch.randn(m, n, generator=g)
+    attn = torch.rand(batch, length, generator=g)
+    gpool = torch.randn(batch, k + 8, generator=g)[:, :k]          # a column slice: ldgp > k
+    hist = torch.randint(1, vocab, (batch, length), generator=g)
+    hist[torch.rand(batch, length, generator=g) < 0.25] = 0
+    hist[0, 1], hist[-1, -1] = vocab, -5
+    gx = gy.double() @ w.double() + attn.double().reshape(m, 1) * gpool.double().repeat_interleave(length, 0)
+    flat = hist.reshape(-1)
+    ok = (flat >= 0) & (flat < vocab)
+    want = torch.zeros(vocab, k, dtype=torch.float64).index_add_(0, flat[ok], gx[ok])
+    base = torch.randn(vocab, k, generator=g)
+    table = base.clone().to(DEV)
+    ops.linear_dx_scatter(w.to(DEV), gy.to(DEV), hist.to(DEV).reshape(-1), attn.to(DEV).reshape(-1), gpool.to(DEV),
+                          length, table)
+    torch.testing.assert_close(table.cpu(), (want + base.double()).float(), rtol=1e-5, atol=2e-4)
+
+
 @pytest.mark.parametrize("m,k", [(5000, 64), (333, 16), (70001, 36), (9, 8)])
 def test_linear_n1_bwd_masked_in_place(ops, m, k):
     # DIN's score layer (model/din.py:46): gx = (gy w) * relu'(x) written over x; gw += gy^T x; gb += sum gy
