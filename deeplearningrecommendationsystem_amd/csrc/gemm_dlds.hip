@@ -17,6 +17,8 @@
 // (finite, multiplied by zero).
 #include "ctr_common.h"
 
+#include <type_traits>
+
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -36,6 +38,8 @@ struct DldsArgs {
   int res_group;        // > 1: residual row of output row i is i / res_group (one row per group of consecutive rows)
   CtrFastDiv res_div;
   uint32_t* mask; int64_t ldmask;  // optional: bit (j & 31) of mask[i*ldmask + j/32] = (Y[i,j] > 0); needs n % 32 == 0
+  // optional single-unit layer on top (n <= 32*NT: the workgroup holds whole rows): dot_out[i] = Y[i,:] . dot_w + dot_b[0]
+  const float* dot_w; const float* dot_b; float* dot_out; int64_t lddot;
 };
 
 // s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14)
@@ -117,6 +121,14 @@ gemm_fwd_dlds_kernel(const DldsArgs a) {
     const int64_t j = j0 + 32 * n + (lane0 & 31);
     bj[n] = a.bias && j < a.n ? a.bias[j] : 0.0f;
   }
+  float dwj[NT];   // the head's weights of this lane's columns (zero past n: those columns add nothing)
+  float dotb = 0.0f;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int64_t j = j0 + 32 * n + (lane0 & 31);
+    dwj[n] = a.dot_out && j < a.n ? a.dot_w[j] : 0.0f;
+  }
+  if (a.dot_out && a.dot_b) dotb = a.dot_b[0];
   wait_vmcnt<0>();  // ... and landed before the ring starts, so that no later use of bj waits on the queue
 
   auto advance = [&](int64_t& t, int& k) {
@@ -221,6 +233,9 @@ gemm_fwd_dlds_kernel(const DldsArgs a) {
       stage = stage + 1 == kStages ? 0 : stage + 1;
     }
     // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float pdot[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) pdot[e] = 0.0f;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       const int64_t j = j0 + 32 * n + r;
@@ -259,6 +274,7 @@ gemm_fwd_dlds_kernel(const DldsArgs a) {
           const int64_t i = i0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h;
           const float o = ctr_act(v[e], a.act);
           if (i < a.m) ctr_stg(a.y + i * a.ldy + j, o);
+          pdot[e] = fmaf(o, dwj[n], pdot[e]);
           if (a.mask) {
             const uint64_t bal = __ballot(o > 0.0f);
             const uint32_t cand = (r & 4) ? (uint32_t)(bal >> 32) : (uint32_t)bal;
@@ -268,6 +284,28 @@ gemm_fwd_dlds_kernel(const DldsArgs a) {
         if (a.mask && h == 0 && i0 + 32 * wave + r < a.m)
           a.mask[(i0 + 32 * wave + r) * a.ldmask + ((j0 + 32 * n) >> 5)] = word;
       }
+    }
+    if (a.dot_out) {
+      // transposed reduction over the 32 columns a half-wave holds: lanes r and r ^ s swap half of their values,
+      // so after four stages lane r holds register r >> 1, summed over 16 lanes, and one more exchange finishes it
+      // (16 shuffles for 16 rows instead of 16 five-step reductions)
+      auto stage = [&](auto keepv, int bit, int xr) __attribute__((always_inline)) {
+        constexpr int KEEP = decltype(keepv)::value;
+#pragma unroll
+        for (int q = 0; q < KEEP; ++q) {
+          const float send = bit ? pdot[q] : pdot[q + KEEP];
+          const float keep = bit ? pdot[q + KEEP] : pdot[q];
+          pdot[q] = keep + __shfl_xor(send, xr, 64);
+        }
+      };
+      stage(std::integral_constant<int, 8>{}, r & 16, 16);
+      stage(std::integral_constant<int, 4>{}, r & 8, 8);
+      stage(std::integral_constant<int, 2>{}, r & 4, 4);
+      stage(std::integral_constant<int, 1>{}, r & 2, 2);
+      const float t = pdot[0] + __shfl_xor(pdot[0], 1, 64);
+      const int e = r >> 1;
+      const int64_t i = i0 + 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if ((r & 1) == 0 && i < a.m) a.dot_out[i * a.lddot] = t + dotb;
     }
   }
 }
@@ -280,7 +318,8 @@ bool ctr_gemm_dlds_ok(const float* x, int64_t ldx, const float* w, int64_t ldw, 
 
 static int launch_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* res,
                       int64_t ldr, float* y, int64_t ldy, int64_t m, int n, int k, int act, hipStream_t st,
-                      int res_group = 1, uint32_t* mask = nullptr, int64_t ldmask = 0) {
+                      int res_group = 1, uint32_t* mask = nullptr, int64_t ldmask = 0, const float* dot_w = nullptr,
+                      const float* dot_b = nullptr, float* dot_out = nullptr, int64_t lddot = 0) {
   const int nt = n <= 32 ? 1 : (n <= 64 ? 2 : 4);
   const int64_t mtiles = ctr_ceil_div(m, kBM);
   const int64_t ny = ctr_ceil_div(n, 32 * nt);
@@ -291,7 +330,8 @@ static int launch_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, 
   CTR_REQUIRE(res_group >= 1 && (res_group == 1 || m < (1ll << 32)), CTR_ELIMIT);
   CTR_REQUIRE(!mask || (n % 32 == 0 && ldmask >= n / 32), CTR_EINVAL);
   const DldsArgs a{x, ldx, w, ldw, bias, res, ldr, y, ldy, m, n, (int64_t)k, act, res_group,
-                   ctr_fastdiv((uint32_t)res_group), mask, ldmask};
+                   ctr_fastdiv((uint32_t)res_group), mask, ldmask, dot_w, dot_b, dot_out, lddot};
+  CTR_REQUIRE(!dot_out || (ny == 1 && dot_w), CTR_EINVAL);  // the head needs whole rows in one workgroup
   const dim3 grid((unsigned)gx, (unsigned)ny);
   if (nt == 1) hipLaunchKernelGGL(gemm_fwd_dlds_kernel<1>, grid, dim3(kThreads), 0, st, a);
   else if (nt == 2) hipLaunchKernelGGL(gemm_fwd_dlds_kernel<2>, grid, dim3(kThreads), 0, st, a);
@@ -336,4 +376,18 @@ extern "C" int ctr_linear_group_fwd(const float* x, int64_t ldx, const float* w,
   CTR_REQUIRE(!mask || (n % 32 == 0 && ldmask >= n / 32), CTR_EINVAL);
   return ctr_gemm_dlds_fwd_group(x, ldx, w, ldw, bias, res, ldr, group, y, ldy, m, n, k, act, (hipStream_t)stream, mask,
                                  ldmask);
+}
+
+// C ABI (include/ctrhip.h): Y = act(X W^T + b), and a single-unit layer on top of it in the same pass:
+// out[i] = Y[i, :] . u + c[0]   (DIN: attention layer 2 and the score layer, model/din.py:45-46)
+extern "C" int ctr_linear_fwd_dot(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y,
+                                  int64_t ldy, const float* u, const float* c, float* out, int64_t ldout, int64_t m,
+                                  int n, int k, int act, void* stream) {
+  CTR_REQUIRE(m >= 0 && n >= 1 && k >= 1, CTR_EINVAL);
+  if (m == 0) return CTR_OK;
+  CTR_REQUIRE(x && w && y && u && out && ldx >= k && ldw >= k && ldy >= n && ldout >= 1, CTR_EINVAL);
+  CTR_REQUIRE(act >= CTR_ACT_NONE && act <= CTR_ACT_SIGMOID, CTR_EINVAL);
+  CTR_REQUIRE(ctr_gemm_dlds_ok(x, ldx, w, ldw, m, n, k) && n <= 128, CTR_ELIMIT);
+  return launch_fwd(x, ldx, w, ldw, bias, nullptr, 0, y, ldy, m, n, k, act, (hipStream_t)stream, 1, nullptr, 0, u, c, out,
+                    ldout);
 }

@@ -186,8 +186,12 @@ class DIN(SequenceModel):
         n1 = w1.shape[0]
         bits = torch.empty((batch * length, n1 // 32), dtype=torch.int32, device=dev) if n1 % 32 == 0 else None
         z1 = ops.linear_group_fwd(hrows, wf[0], None, u, length, ACT_RELU, sign_bits=bits)   # (B*L, n1)
-        h2 = ops.linear_fwd(z1, att[1].weight, att[1].bias, ACT_RELU)
-        score = ops.linear_fwd(h2, att[2].weight, att[2].bias, ACT_NONE)
+        if att[1].weight.shape[0] <= 128 and att[2].weight.shape[0] == 1 and att[2].act == ACT_NONE:
+            # the score layer rides in layer 2's epilogue (its rows are whole in a workgroup)
+            h2, score = ops.linear_fwd_dot(z1, att[1].weight, att[1].bias, ACT_RELU, att[2].weight, att[2].bias)
+        else:
+            h2 = ops.linear_fwd(z1, att[1].weight, att[1].bias, ACT_RELU)
+            score = ops.linear_fwd(h2, att[2].weight, att[2].bias, ACT_NONE)
         attn = torch.empty((batch, length), dtype=torch.float32, device=dev)
         ops.din_pool_fwd(score, hrows, batch, length, dim, attn, fcin[:, :dim], summed=True)
         fc_acts = ops.mlp_fwd(fcin, fc)

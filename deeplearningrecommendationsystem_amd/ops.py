@@ -885,6 +885,23 @@ def linear_dx_masked(w, y, gy, act: int, xin, act_in: int, gx, gsum=None, group:
     _lib.check(rc, "ctr_linear_dx_masked")
 
 
+def linear_fwd_dot(x, w, b, act: int, u, c):
+    """(y, out) with y = act(x @ w.T + b) and out = y @ u.T + c for a single-unit ``u`` (1, n): the second layer is
+    formed in the first one's epilogue (n <= 128), so y is not re-read for it"""
+    x, w, u = _mat(x, "x"), _mat(w, "w"), _mat(u, "u")
+    m, k = x.shape
+    n = w.shape[0]
+    if u.shape != (1, n):
+        raise ValueError(f"linear_fwd_dot: u must be (1, {n})")
+    y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    out = torch.empty((m, 1), dtype=torch.float32, device=x.device)
+    rc = _timed(f"linear_fwd_dot[{m}x{n}x{k}]", lambda: (4 * (m * k + n * k + n + m * n + m), 2 * m * n * (k + 1)),
+                _lib.load().ctr_linear_fwd_dot, x.data_ptr(), _ld(x), w.data_ptr(), _ld(w), _lib.ptr(b), y.data_ptr(),
+                _ld(y), u.data_ptr(), _lib.ptr(c), out.data_ptr(), 1, m, n, k, act, _lib.stream_ptr())
+    _lib.check(rc, "ctr_linear_fwd_dot")
+    return y, out
+
+
 def linear_dx_scatter(w, gy, idx, attn, gpool, group: int, gtable) -> None:
     """gtable[idx[i]] += gy[i] @ w + attn[i] * gpool[i // group]: the input gradient of a layer whose input rows were
     gathered from ``gtable``'s table, added where the rows came from without storing the (m, k) gradient (DIN)"""

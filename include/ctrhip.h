@@ -503,6 +503,12 @@ int ctr_linear_dx_masked(const float* w, int64_t ldw, const float* y, int64_t ld
                          int act, const float* xin /*nullable with xmask*/, int64_t ldxin, int act_in,
                          const uint32_t* xmask /*nullable*/, int64_t ldxmask, float* gx, int64_t ldgx,
                          float* gsum /*nullable*/, int64_t ldgsum, int group, int64_t m, int n, int k, void* stream);
+/* a layer and the single-unit layer on top of it in one pass (DIN attention layers 2 and 3, model/din.py:45-46):
+ *   y = act(x W^T + bias)   (m, n) stored as usual,     out[i*ldout] = y[i, :] . u + c[0]     (c nullable)
+ * n <= 128: a workgroup holds whole output rows and reduces them in its epilogue. */
+int ctr_linear_fwd_dot(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias /*nullable*/,
+                       float* y, int64_t ldy, const float* u, const float* c /*nullable*/, float* out, int64_t ldout,
+                       int64_t m, int n, int k, int act, void* stream);
 /* input gradient of DIN's first attention layer on the E-wide operand, scattered straight into the item table's
  * gradient (model/din.py:35-44 backward: the history rows h = table[hist] receive gX plus the pooling's share):
  *   table[idx[i], :] += gy[i, :] W + attn[i] * gpool[i / group, :]          i < m;  W is (n, k), table (vocab, k)

@@ -928,6 +928,22 @@ def test_linear_dx_masked_and_group_sums(ops, m, n, k, group):
     torch.testing.assert_close(gx2.cpu(), (gy.double() @ w.double()).float(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("m,n,k,act", [(1000, 64, 128, "ACT_RELU"), (333, 128, 64, "ACT_NONE"), (4097, 40, 24, "ACT_SIGMOID"),
+                                       (65, 8, 16, "ACT_RELU")])
+def test_linear_fwd_dot_forms_the_single_unit_layer_in_the_epilogue(ops, m, n, k, act):
+    # DIN attention layers 2 + 3 (model/din.py:45-46): y = act(x W^T + b) stored, out = y u^T + c from the same tile
+    g = torch.Generator().manual_seed(m + n)
+    x, w, b = torch.randn(m, k, generator=g), torch.randn(n, k, generator=g) / k ** 0.5, torch.randn(n, generator=g)
+    u, c = torch.randn(1, n, generator=g), torch.randn(1, generator=g)
+    f = {"ACT_RELU": torch.relu, "ACT_NONE": lambda t: t, "ACT_SIGMOID": torch.sigmoid}[act]
+    want_y = f(x.double() @ w.double().T + b.double())
+    want_o = want_y @ u.double().T + c.double()
+    y, out = ops.linear_fwd_dot(x.to(DEV), w.to(DEV), b.to(DEV), getattr(ops, act), u.to(DEV), c.to(DEV))
+    torch.testing.assert_close(y.cpu(), want_y.float(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out.cpu(), want_o.float(), rtol=1e-5, atol=2e-5)
+    assert torch.equal(y.cpu(), ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), getattr(ops, act)).cpu())
+
+
 @pytest.mark.parametrize("batch,length,n,k,vocab", [(40, 100, 128, 64, 500), (7, 33, 64, 32, 50), (3, 130, 16, 128, 1000)])
 def test_linear_dx_scatter_adds_the_input_gradient_where_the_rows_came_from(ops, batch, length, n, k, vocab):
     # DIN's history gradient (model/din.py:35-44 backward): table[hist[i]] += gy[i] W + attn[i] * gpool[i // L];
