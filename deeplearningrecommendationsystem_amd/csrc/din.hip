@@ -219,6 +219,21 @@ pool_fwd_kernel(const SeqGeom g, const float* __restrict__ score, const float* _
 // LDS (len <= kPoolStage: 320 -> us on 32768 x 100 x 64, the second sweep missed L2 with 2048 waves x 25 KB in
 // flight); longer histories take a second sweep that recomputes ga_l bit-identically.
 constexpr int kPoolStage = 512;
+// sum over the 16 lanes of a DPP row, result in every lane: four rotate-and-add steps on the VALU.  The xor-shuffle
+// form is a ds_bpermute per step -- 3.7 M of them per DIN backward through the LDS crossbar of 256 CUs.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, true));  // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, true));  // row_ror:1
+  return v;
+}
+__device__ __forceinline__ float quad_sum4(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  return v;
+}
+
 template <int VEC>
 __global__ void __launch_bounds__(kBlock)
 pool_bwd_kernel(const SeqGeom g, const float* __restrict__ attn, const float* __restrict__ hsrc, int64_t ldh,
@@ -260,7 +275,10 @@ pool_bwd_kernel(const SeqGeom g, const float* __restrict__ attn, const float* __
           for (int u = 0; u < 4; ++u) {
             const int l = l0 + u * rows_per_iter + rsub;
             float ga = ga4[u];
-            for (int o = g.lpr >> 1; o > 0; o >>= 1) ga += __shfl_xor(ga, o, 64);
+            if (g.lpr == 16) ga = row16_sum(ga);   // a row's lanes are one DPP row: VALU rotations, no LDS crossbar
+            else if (g.lpr == 4) ga = quad_sum4(ga);
+            else
+              for (int o = g.lpr >> 1; o > 0; o >>= 1) ga += __shfl_xor(ga, o, 64);
             if (l < g.len && sub == 0) {
               if (pass == 0) {
                 dotsum = fmaf(ab4[u], ga, dotsum);

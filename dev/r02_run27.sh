@@ -1,7 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out/r02
-timeout -k 10 400 python -m pytest tests/test_gpu_ops.py tests/test_gpu_models.py tests/test_gpu_fullsize.py tests/test_gpu_sparse.py -q -m gpu -k "linear or din or DIN" 2>&1 | tail -4
-for w in "din" "din --sparse" "deepfm" "pnn26"; do
+timeout -k 10 400 python -m pytest tests/test_gpu_ops.py tests/test_gpu_models.py tests/test_gpu_fullsize.py tests/test_gpu_sparse.py -q -m gpu -k "din or DIN or dien or DIEN or afm or attention" 2>&1 | tail -4
+for w in "din" "din --sparse" "dien"; do
   tag=$(echo $w | tr -d ' -')
   timeout -k 10 300 python bench.py --workload $w --no-gather-leg --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/r02/bench_${tag}.json 2> gpurun_out/r02/bench_$tag.err || tail -5 gpurun_out/r02/bench_$tag.err
 python - <<PY
