@@ -15,7 +15,7 @@ import torch  # noqa: F401  (maps libamdhip64 first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTRHIP_LIB", os.path.join(_HERE, "libctrhip.so"))  # env override: A/B builds
-ABI_VERSION = 24
+ABI_VERSION = 25
 DIN_TRIPLE, DIN_PAIR, DIN_H = 0, 1, 2  # layouts of the DIN attention operand (include/ctrhip.h)
 
 CTR_MAX_FIELDS = 32
@@ -133,6 +133,8 @@ SIGNATURES = {
     "ctr_din_scatter_bwd": (_i, [_p, _l, _l, _i, _i, _p, _l, _p, _p, _l, _i, _p, _p]),
     "ctr_linear_group_fwd": (_i, [_p, _l, _p, _l, _p, _p, _l, _i, _p, _l, _p, _l, _l, _i, _i, _i, _p]),
     "ctr_linear_dx_masked": (_i, [_p, _l, _p, _l, _p, _l, _i, _p, _l, _i, _p, _l, _p, _l, _p, _l, _i, _l, _i, _i, _p]),
+    "ctr_gru_fused_fwd": (_i, [_p, _l, _p, _p, _p, _p, _l, _i, _i, _p, _p, _l, _p]),
+    "ctr_gru_fused_bwd": (_i, [_p, _l, _p, _p, _p, _p, _p, _l, _i, _i, _p, _l, _p, _l, _p, _p, _p, _p, _p, _l, _p]),
     "ctr_linear_fwd_dot": (_i, [_p, _l, _p, _l, _p, _p, _l, _p, _p, _p, _l, _l, _i, _i, _i, _p]),
     "ctr_linear_dx_scatter": (_i, [_p, _l, _p, _l, _p, _p, _p, _l, _i, _p, _l, _l, _i, _i, _p]),
     "ctr_linear_n1_bwd_masked": (_i, [_p, _l, _p, _p, _l, _i, _p, _l, _p, _p, _l, _i, _p, _l, _p]),

@@ -1,6 +1,8 @@
 """DIEN -- counterpart of the reference's model/dien.py:8-81."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 from torch.nn.init import xavier_normal_
@@ -9,6 +11,10 @@ from .. import ops
 from ..ops import ACT_NONE, Layer
 from .din import (SequenceModel, _zero_grads, attention_layers, fc_layers, fold_attention_weight,
                   unfold_attention_grad)
+
+# the GRU kernels form the input projection themselves (ctr_gru_fused_fwd / _bwd); CTR_DIEN_FUSED_GRU=0 keeps the
+# gi GEMM + recurrence + three gradient GEMMs for A/B
+FUSED_GRU = os.environ.get("CTR_DIEN_FUSED_GRU", "1") != "0"
 
 
 class DIN(nn.Module):
@@ -75,9 +81,12 @@ class DIEN(SequenceModel):
         attn = torch.empty((batch, length), dtype=torch.float32, device=dev)
         seq = torch.empty((batch * length, dim), dtype=torch.float32, device=dev)
         ops.din_pool_fwd(att_acts[-1], c, batch, length, dim, attn, seq, summed=False)
-        gi = ops.linear_fwd(seq, w_ih, b_ih)
         hbuf = torch.empty((batch * (length + 1), dim), dtype=torch.float32, device=dev)
-        ops.gru_fwd(gi, w_hh, b_hh, batch, length, dim, hbuf, fcin[:, :dim])
+        # the recurrence kernel forms the input projection itself where it can (E = 16): no (B*L, 3E) gi
+        gi = None
+        if not (FUSED_GRU and ops.gru_fused_fwd(seq, w_ih, b_ih, w_hh, b_hh, batch, length, dim, hbuf, fcin[:, :dim])):
+            gi = ops.linear_fwd(seq, w_ih, b_ih)
+            ops.gru_fwd(gi, w_hh, b_hh, batch, length, dim, hbuf, fcin[:, :dim])
         fc_acts = ops.mlp_fwd(fcin, fc)
         return fc_acts[-1], (att_acts, attn, seq, gi, hbuf, fc_acts, w1f)
 
@@ -96,17 +105,22 @@ class DIEN(SequenceModel):
         zeros = _zero_grads(self, params)
         zeros[id(w1f)] = torch.zeros_like(w1f)
         fc_grads, gfcin = ops.mlp_bwd(fc_acts, fc, gprob, None, zeros=zeros)
-        dgi = torch.empty((batch * length, 3 * dim), dtype=torch.float32, device=dev)
-        dgh = torch.empty((batch * (length + 1), 3 * dim), dtype=torch.float32, device=dev)
-        ops.gru_bwd(gi, w_hh, b_hh, hbuf, batch, length, dim, gfcin[:, :dim], dgi, dgh)
         g_w_ih, g_w_hh, g_b_ih, g_b_hh = (zeros[id(t)] for t in (w_ih, w_hh, b_ih, b_hh))
         gseq = torch.empty_like(seq)
-        ops.linear_bwd(seq, w_ih, None, dgi, ACT_NONE, gseq, g_w_ih, g_b_ih)
-        # dW_hh = sum_{b,t} dgh_t (x) h_{t-1}: rows r+1 of dgh against rows r of hbuf; the
-        # zero row at the head of every sample makes the pairs that straddle samples vanish
-        rows = batch * (length + 1) - 1
-        if rows > 0:
-            ops.linear_bwd(hbuf[:rows], w_hh, None, dgh[1:], ACT_NONE, None, g_w_hh, g_b_hh)
+        if gi is None:
+            # input gradient and the four parameter gradients straight out of the recurrence's backward
+            ops.gru_fused_bwd(seq, w_ih, b_ih, w_hh, b_hh, hbuf, batch, length, dim, gfcin[:, :dim], gseq, g_w_ih,
+                              g_b_ih, g_w_hh, g_b_hh)
+        else:
+            dgi = torch.empty((batch * length, 3 * dim), dtype=torch.float32, device=dev)
+            dgh = torch.empty((batch * (length + 1), 3 * dim), dtype=torch.float32, device=dev)
+            ops.gru_bwd(gi, w_hh, b_hh, hbuf, batch, length, dim, gfcin[:, :dim], dgi, dgh)
+            ops.linear_bwd(seq, w_ih, None, dgi, ACT_NONE, gseq, g_w_ih, g_b_ih)
+            # dW_hh = sum_{b,t} dgh_t (x) h_{t-1}: rows r+1 of dgh against rows r of hbuf; the
+            # zero row at the head of every sample makes the pairs that straddle samples vanish
+            rows = batch * (length + 1) - 1
+            if rows > 0:
+                ops.linear_bwd(hbuf[:rows], w_hh, None, dgh[1:], ACT_NONE, None, g_w_hh, g_b_hh)
         gscore = torch.empty((batch * length, 1), dtype=torch.float32, device=dev)
         ops.din_pool_bwd(attn, c, batch, length, dim, gseq, False, gscore)
         att_grads, gc = ops.mlp_bwd(att_acts, att, gscore, None, zeros=zeros)

@@ -999,6 +999,35 @@ def gru_fwd(gi, w_hh, b_hh, batch, length, dim, hbuf, last) -> None:
     _lib.check(rc, "ctr_gru_fwd")
 
 
+def gru_fused_fwd(x, w_ih, b_ih, w_hh, b_hh, batch, length, dim, hbuf, last) -> bool:
+    """the GRU with its input projection inside (x rows instead of gi).  False: shape not taken, nothing ran --
+    form gi with ``linear_fwd`` and call ``gru_fwd``."""
+    x = _mat(x, "x")
+    rc = _timed("gru_fused_fwd", lambda: (4 * batch * length * 2 * dim, 12 * batch * length * dim * dim),
+                _lib.load().ctr_gru_fused_fwd, x.data_ptr(), _ld(x), w_ih.data_ptr(), b_ih.data_ptr(), w_hh.data_ptr(),
+                b_hh.data_ptr(), batch, length, dim, hbuf.data_ptr(), _lib.ptr(last),
+                _ld(last) if last is not None else 0, _lib.stream_ptr())
+    if rc in _REFUSED:
+        if _profiler is not None and _profiler.records and _profiler.records[-1][0] == "gru_fused_fwd":
+            _profiler.records.pop()
+        return False
+    _lib.check(rc, "ctr_gru_fused_fwd")
+    return True
+
+
+def gru_fused_bwd(x, w_ih, b_ih, w_hh, b_hh, hbuf, batch, length, dim, glast, gx, gw_ih, gb_ih, gw_hh, gb_hh) -> None:
+    """backward of ``gru_fused_fwd``: gx = dgi W_ih and the four parameter gradients (accumulated), nothing of size
+    3*dim per step stored"""
+    x, glast, gx = _mat(x, "x"), _mat(glast, "glast"), _mat(gx, "gx")
+    ws = _scratch(x.device)
+    rc = _timed("gru_fused_bwd", lambda: (4 * batch * length * 3 * dim, 36 * batch * length * dim * dim),
+                _lib.load().ctr_gru_fused_bwd, x.data_ptr(), _ld(x), w_ih.data_ptr(), b_ih.data_ptr(), w_hh.data_ptr(),
+                b_hh.data_ptr(), hbuf.data_ptr(), batch, length, dim, glast.data_ptr(), _ld(glast), gx.data_ptr(),
+                _ld(gx), gw_ih.data_ptr(), gb_ih.data_ptr(), gw_hh.data_ptr(), gb_hh.data_ptr(), ws.data_ptr(),
+                ws.numel(), _lib.stream_ptr())
+    _lib.check(rc, "ctr_gru_fused_bwd")
+
+
 def gru_bwd(gi, w_hh, b_hh, hbuf, batch, length, dim, glast, dgi, dgh) -> None:
     gi, glast = _mat(gi, "gi"), _mat(glast, "glast")
     rc = _timed("gru_bwd", lambda: (4 * batch * length * 10 * dim, 12 * batch * length * dim * dim),

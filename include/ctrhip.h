@@ -322,6 +322,19 @@ int ctr_gru_fwd(const float* gi, int64_t ldgi, const float* w_hh, const float* b
 int ctr_gru_bwd(const float* gi, int64_t ldgi, const float* w_hh, const float* b_hh, const float* hbuf,
                 int64_t batch, int len, int dim, const float* glast, int64_t ldgl, float* dgi, float* dgh,
                 void* stream);
+/* The same GRU with the input projection inside: x (batch*len, dim) rows instead of gi, W_ih (3*dim, dim), b_ih.
+ * Forward writes hbuf / last as ctr_gru_fwd.  Backward recomputes the projection and leaves, instead of dgi / dgh,
+ *   gx (batch*len, dim) = dgi W_ih,   gw_ih += dgi^T X,  gb_ih += sum dgi,  gw_hh += dgh^T H_prev,  gb_hh += sum dgh
+ * (weight sums per workgroup in registers, fixed-order partials through the workspace: >= 256 * 1632 floats).
+ * dim == 16 and batch % 4 == 0 only: CTR_ELIMIT otherwise with nothing enqueued -- use ctr_linear_fwd +
+ * ctr_gru_fwd / ctr_gru_bwd + ctr_linear_bwd as above. */
+int ctr_gru_fused_fwd(const float* x, int64_t ldx, const float* w_ih, const float* b_ih, const float* w_hh,
+                      const float* b_hh, int64_t batch, int len, int dim, float* hbuf, float* last /*nullable*/,
+                      int64_t ldl, void* stream);
+int ctr_gru_fused_bwd(const float* x, int64_t ldx, const float* w_ih, const float* b_ih, const float* w_hh,
+                      const float* b_hh, const float* hbuf, int64_t batch, int len, int dim, const float* glast,
+                      int64_t ldgl, float* gx, int64_t ldgx, float* gw_ih, float* gb_ih, float* gw_hh, float* gb_hh,
+                      float* workspace, int64_t workspace_floats, void* stream);
 
 /* ------------------------------------------------------------------------
  * A whole stack of narrow nn.Linear(+activation) layers in one launch (forward) and

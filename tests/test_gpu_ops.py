@@ -928,6 +928,42 @@ def test_linear_dx_masked_and_group_sums(ops, m, n, k, group):
     torch.testing.assert_close(gx2.cpu(), (gy.double() @ w.double()).float(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("batch,length", [(64, 100), (8, 1), (12, 7), (260, 33)])
+def test_gru_with_the_input_projection_inside_matches_torch_gru(ops, batch, length):
+    # DIEN interest evolution (model/dien.py:47,61: nn.GRU(E, E, batch_first=True), h0 = 0) at E = 16: forward
+    # states, last state, input gradient and the four parameter gradients against torch autograd on the CPU
+    dim = 16
+    g = torch.Generator().manual_seed(batch + length)
+    gru = torch.nn.GRU(dim, dim, batch_first=True)
+    with torch.no_grad():
+        for prm in gru.parameters():
+            prm.copy_(torch.randn(prm.shape, generator=g) * 0.3)
+    x = torch.randn(batch, length, dim, generator=g, requires_grad=True)
+    out, hn = gru(x)
+    glast = torch.randn(batch, dim, generator=g)
+    (hn[0] * glast).sum().backward()
+    w_ih, w_hh, b_ih, b_hh = (t.detach().to(DEV) for t in (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0))
+    xd = x.detach().reshape(batch * length, dim).to(DEV)
+    hbuf = torch.full((batch * (length + 1), dim), float("nan"), device=DEV)
+    last = torch.empty(batch, dim, device=DEV)
+    assert ops.gru_fused_fwd(xd, w_ih, b_ih, w_hh, b_hh, batch, length, dim, hbuf, last)
+    hb = hbuf.view(batch, length + 1, dim).cpu()
+    assert torch.equal(hb[:, 0], torch.zeros(batch, dim))
+    torch.testing.assert_close(hb[:, 1:], out.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(last.cpu(), hn[0].detach(), rtol=1e-5, atol=1e-5)
+    gx = torch.full((batch * length, dim), float("nan"), device=DEV)
+    gw_ih, gw_hh = torch.zeros_like(w_ih), torch.zeros_like(w_hh)
+    gb_ih, gb_hh = torch.zeros_like(b_ih), torch.zeros_like(b_hh)
+    ops.gru_fused_bwd(xd, w_ih, b_ih, w_hh, b_hh, hbuf, batch, length, dim, glast.to(DEV), gx, gw_ih, gb_ih, gw_hh, gb_hh)
+    torch.testing.assert_close(gx.cpu().view(batch, length, dim), x.grad, rtol=1e-4, atol=1e-5)
+    for got, want in ((gw_ih, gru.weight_ih_l0), (gw_hh, gru.weight_hh_l0), (gb_ih, gru.bias_ih_l0), (gb_hh, gru.bias_hh_l0)):
+        torch.testing.assert_close(got.cpu(), want.grad, rtol=1e-4, atol=1e-4 * max(1.0, (batch * length) ** 0.5 / 30))
+    # other widths are refused with nothing enqueued
+    assert not ops.gru_fused_fwd(torch.zeros(8, 8, device=DEV), torch.zeros(24, 8, device=DEV), torch.zeros(24, device=DEV),
+                                 torch.zeros(24, 8, device=DEV), torch.zeros(24, device=DEV), 4, 2, 8,
+                                 torch.zeros(12, 8, device=DEV), None)
+
+
 @pytest.mark.parametrize("m,n,k,act", [(1000, 64, 128, "ACT_RELU"), (333, 128, 64, "ACT_NONE"), (4097, 40, 24, "ACT_SIGMOID"),
                                        (65, 8, 16, "ACT_RELU")])
 def test_linear_fwd_dot_forms_the_single_unit_layer_in_the_epilogue(ops, m, n, k, act):
