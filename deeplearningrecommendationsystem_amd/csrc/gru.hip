@@ -167,7 +167,22 @@ gru_bwd_kernel(const GruGeom g, const float* __restrict__ gi, int64_t ldgi, cons
 // neighbouring lanes with DPP row_share: no LDS, no barrier, ~3x fewer instructions per step.
 template <int K>
 __device__ __forceinline__ float row_bcast(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + K, 0xf, 0xf, false));
+  // mov_dpp, not update_dpp(old = 0): every lane of a row_share has a source, and an "old" value costs a v_mov per
+  // broadcast and keeps the DPP combiner from folding the broadcast into the FMA that uses it
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x150 + K, 0xf, 0xf, true));
+}
+// acc += w * (lane K of the row's value of src): the broadcast rides on the FMA as a DPP operand (v_fmac_f32_dpp) --
+// one instruction instead of a v_mov_b32_dpp and a v_fmac.  The compiler's combiner does not do this for a broadcast
+// with three to six users.  The asm is opaque to the hazard recogniser: a DPP source must not have been written by
+// the two VALU instructions before it (settle() below).
+template <int K>
+__device__ __forceinline__ void fmac_bcast(float& acc, float src, float w) {
+  asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(w), "n"(K));
+}
+// two wait states between the VALU writes of these values and their first DPP read; ties the later asm to them
+__device__ __forceinline__ void settle(float& a) { asm volatile("s_nop 1" : "+v"(a)); }
+__device__ __forceinline__ void settle(float& a, float& b, float& c, float& d) {
+  asm volatile("s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 #define CTR_ROW16(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11) OP(12) OP(13) OP(14) OP(15)
 
@@ -318,8 +333,9 @@ gru16_fused_fwd_kernel(int64_t batch, int len, const float* __restrict__ x, int6
     for (int u = 0; u < 4; ++u) xc[u] = u < len ? ctr_ldg(xs + (int64_t)u * ldx) : 0.0f;
     float gr = cr0, gz = cz0, gn = cn0;                // input projection of step t
     {
-      const float x0 = xc[0];
-#define CTR_STEP(K) { const float xk = row_bcast<K>(x0); gr = fmaf(ur[K], xk, gr); gz = fmaf(uz[K], xk, gz); gn = fmaf(un[K], xk, gn); }
+      float x0 = xc[0];
+      settle(x0);
+#define CTR_STEP(K) { fmac_bcast<K>(gr, x0, ur[K]); fmac_bcast<K>(gz, x0, uz[K]); fmac_bcast<K>(gn, x0, un[K]); }
       CTR_ROW16(CTR_STEP)
 #undef CTR_STEP
     }
@@ -330,13 +346,15 @@ gru16_fused_fwd_kernel(int64_t batch, int len, const float* __restrict__ x, int6
       for (int u = 0; u < 4; ++u) {
         const int t = t0 + u;
         if (t >= len) break;
-        const float x1 = u < 3 ? xc[u < 3 ? u + 1 : 0] : xq[0];   // x_{t+1}
+        float x1 = u < 3 ? xc[u < 3 ? u + 1 : 0] : xq[0];   // x_{t+1}
         float nr = cr0, nz = cz0, nn = cn0;              // projection of step t+1: independent of h
-#define CTR_STEP(K) { const float xk = row_bcast<K>(x1); nr = fmaf(ur[K], xk, nr); nz = fmaf(uz[K], xk, nz); nn = fmaf(un[K], xk, nn); }
+        settle(x1);
+#define CTR_STEP(K) { fmac_bcast<K>(nr, x1, ur[K]); fmac_bcast<K>(nz, x1, uz[K]); fmac_bcast<K>(nn, x1, un[K]); }
         CTR_ROW16(CTR_STEP)
 #undef CTR_STEP
         float ar = br, az = bz, an = bn;
-#define CTR_STEP(K) { const float hk = row_bcast<K>(h); ar = fmaf(wr[K], hk, ar); az = fmaf(wz[K], hk, az); an = fmaf(wn[K], hk, an); }
+        settle(h);
+#define CTR_STEP(K) { fmac_bcast<K>(ar, h, wr[K]); fmac_bcast<K>(az, h, wz[K]); fmac_bcast<K>(an, h, wn[K]); }
         CTR_ROW16(CTR_STEP)
 #undef CTR_STEP
         const float r = ctr_sigmoid(gr + ar);
@@ -418,11 +436,12 @@ gru16_fused_bwd_kernel(int64_t batch, int len, const float* __restrict__ x, int6
       for (int u = 0; u < 4; ++u) {
       const int t = thi - u;
       if (t < 0) break;
-      const float xt = xc[u], hp = hc[u];
+      float xt = xc[u], hp = hc[u];
+      settle(xt);
+      settle(hp);
       float gr = cr0, gz = cz0, gn = cn0, ar = br, az = bz, an = bn;
-#define CTR_STEP(K) { const float xk = row_bcast<K>(xt), hk = row_bcast<K>(hp);                                   \
-                      gr = fmaf(ur[K], xk, gr); gz = fmaf(uz[K], xk, gz); gn = fmaf(un[K], xk, gn);               \
-                      ar = fmaf(wr[K], hk, ar); az = fmaf(wz[K], hk, az); an = fmaf(wn[K], hk, an); }
+#define CTR_STEP(K) { fmac_bcast<K>(gr, xt, ur[K]); fmac_bcast<K>(gz, xt, uz[K]); fmac_bcast<K>(gn, xt, un[K]); \
+                      fmac_bcast<K>(ar, hp, wr[K]); fmac_bcast<K>(az, hp, wz[K]); fmac_bcast<K>(an, hp, wn[K]); }
       CTR_ROW16(CTR_STEP)
 #undef CTR_STEP
       const float r = ctr_sigmoid(gr + ar);
@@ -430,10 +449,11 @@ gru16_fused_bwd_kernel(int64_t batch, int len, const float* __restrict__ x, int6
       const float n = tanhf(gn + r * an);
       const float dz = dh * (hp - n);
       const float dn = dh * (1.0f - z);
-      const float dan = dn * (1.0f - n * n);
-      const float dar = dan * an * r * (1.0f - r);
-      const float daz = dz * z * (1.0f - z);
-      const float dhn = dan * r;
+      float dan = dn * (1.0f - n * n);
+      float dar = dan * an * r * (1.0f - r);
+      float daz = dz * z * (1.0f - z);
+      float dhn = dan * r;
+      settle(dar, daz, dhn, dan);
       mi[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(dar, xt, mi[0], 0, 0, 0);
       mi[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(daz, xt, mi[1], 0, 0, 0);
       mi[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(dan, xt, mi[2], 0, 0, 0);
@@ -443,11 +463,14 @@ gru16_fused_bwd_kernel(int64_t batch, int len, const float* __restrict__ x, int6
       sbr += dar; sbz += daz; sbn += dan; sbhn += dhn;
       // dh_{t-1}[j] = dh_t[j]*z + sum_i W_hh[i][j] dgh_t[i];   dX_t[j] = sum_i W_ih[i][j] dgi_t[i]
       float acc = dh * z, gxj = 0.0f;
-#define CTR_STEP(K) { const float a0 = row_bcast<K>(dar), a1 = row_bcast<K>(daz), a2 = row_bcast<K>(dhn), a3 = row_bcast<K>(dan); \
-                      acc = fmaf(cr[K], a0, acc); acc = fmaf(cz[K], a1, acc); acc = fmaf(cn[K], a2, acc);                       \
-                      gxj = fmaf(vr[K], a0, gxj); gxj = fmaf(vz[K], a1, gxj); gxj = fmaf(vn[K], a3, gxj); }
+      // (three partial sums each: a 48-long dependent chain would be the step's critical path)
+      float acc1 = 0.0f, acc2 = 0.0f, gx1 = 0.0f, gx2 = 0.0f;
+#define CTR_STEP(K) { fmac_bcast<K>(acc, dar, cr[K]); fmac_bcast<K>(acc1, daz, cz[K]); fmac_bcast<K>(acc2, dhn, cn[K]); \
+                      fmac_bcast<K>(gxj, dar, vr[K]); fmac_bcast<K>(gx1, daz, vz[K]); fmac_bcast<K>(gx2, dan, vn[K]); }
       CTR_ROW16(CTR_STEP)
 #undef CTR_STEP
+      acc += acc1 + acc2;
+      gxj += gx1 + gx2;
       gx[(b * len + t) * ldgx + j] = gxj;
       dh = acc;
       }
