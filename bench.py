@@ -312,8 +312,12 @@ def gather_stage_leg(device, reps: int = 30):
 
 
 # kernel label (ops.py) -> kernel name in the rocprofv3 / PMC summaries under profiles/
-KERNEL_NAMES = {"embed_fwd_fast": "embed_ids_fast_kernel", "mlp_fused_bwd": "mlp_bwd_kernel", "mlp_fused_fwd": "mlp_fwd_kernel", "embed_fwd": "embed_fwd_kernel",
-                "embed_bwd": "embed_bwd_kernel", "mf_fwd": "mf_fwd_kernel", "mf_bwd": "mf_bwd_kernel"}
+# label of an event-bracketed call -> the kernel name prefixes it may appear under in the PMC table (first match wins)
+KERNEL_NAMES = {"embed_fwd_fast": ("embed_ids_fast_kernel",), "mlp_fused_bwd": ("mlp_bwd_kernel",),
+                "mlp_fused_fwd": ("mlp_fwd_direct_kernel", "mlp_fwd_kernel"),
+                "embed_fwd": ("embed_rows_fast_kernel", "embed_fwd_kernel"),
+                "embed_bwd": ("seg_reduce_kernel", "embed_bwd_kernel"), "mf_fwd": ("mf_fwd_kernel",),
+                "mf_bwd": ("mf_bwd_kernel",)}
 
 
 # what one event-bracketed C-ABI call covers when it is more than one kernel
@@ -331,17 +335,18 @@ def pmc_traffic(workload, label):
     under-count only when that keeps the total <= 2x the raw reading; None when no pass is committed."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_traffic.json")))
-    name = KERNEL_NAMES.get(label)
-    if not files or name is None:
+    names = KERNEL_NAMES.get(label)
+    if not files or names is None:
         return None
     try:
         table = json.load(open(files[-1]))
     except (OSError, ValueError):
         return None
-    for k, v in table.items():
-        if k.startswith(name):
-            return {"hbm_bytes_raw": v["hbm_bytes_raw"], "hbm_bytes_fetch_x2": v["hbm_bytes_fetchx2"],
-                    "source": os.path.relpath(files[-1], ROOT)}
+    for name in names:
+        for k, v in table.items():
+            if k.startswith(name):
+                return {"hbm_bytes_raw": v["hbm_bytes_raw"], "hbm_bytes_fetch_x2": v["hbm_bytes_fetchx2"],
+                        "kernel": k, "source": os.path.relpath(files[-1], ROOT)}
     return None
 
 
