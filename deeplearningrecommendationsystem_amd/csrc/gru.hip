@@ -10,6 +10,7 @@
 // Backward writes dgi_t and dgh_t for every step; the weight/bias/input gradients are
 // then GEMMs over all (b,t) rows (dW_ih = dgi^T X, dW_hh = dgh^T H_prev, dX = dgi W_ih).
 #include "ctr_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -508,6 +509,292 @@ gru16_fused_bwd_kernel(int64_t batch, int len, const float* __restrict__ x, int6
     out[i] = (s_part[0][i] + s_part[1][i]) + (s_part[2][i] + s_part[3][i]);
 }
 
+// ---- E = 16 on the matrix cores: sixteen samples per wave ------------------------------------------------------------
+// The DPP kernels above spend a step's time issuing 96-192 broadcast FMAs for FOUR samples.  As a matrix product the
+// same work is  P_g (16 units x 16 samples) = W_g (16 x 16) . V (16 units x 16 samples)  -- four v_mfma_f32_16x16x4_f32
+// per gate block, 32 cycles each, for SIXTEEN samples.  What makes it a recurrence without any data movement: the
+// result layout of that instruction (lane (q, n) holds units 4q .. 4q+3 of sample n) is also a legal B-operand layout
+// for the next step if contraction chunk c is taken to be the units {4q + c}: the state registers of a lane ARE its B
+// operands, and W enters as A operands  W_g[lane % 16][4q + c]  (12 registers per matrix).  x_t arrives as one
+// dwordx4 per lane (units 4q .. 4q+3 of its sample) and is a B operand the same way.
+// Gate functions for the matrix-core kernels: a lane evaluates them for four units per step, and expf + IEEE division +
+// ocml's branching tanhf were ~90 instructions per unit (400 of the 500 VALU instructions of a step).  v_exp_f32 and
+// v_rcp_f32 are accurate to 1 ulp of their own operation; through the argument scaling the results carry an absolute
+// error of a few 1e-7, two orders inside the 1e-5 the parity tests allow on states and gradients.
+__device__ __forceinline__ float gate_sigmoid(float z) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * z));
+}
+__device__ __forceinline__ float gate_tanh(float z) {   // 1 - 2 / (1 + e^{2z}); saturates cleanly (rcp(inf) = 0)
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681472f * z));
+}
+
+__global__ void __launch_bounds__(kBlock)
+gru16_mfma_fwd_kernel(int64_t batch, int len, const float* __restrict__ x, int64_t ldx, const float* __restrict__ w_ih,
+                      const float* __restrict__ b_ih, const float* __restrict__ w_hh, const float* __restrict__ b_hh,
+                      float* __restrict__ hbuf, float* __restrict__ last, int64_t ldl) {
+  constexpr int E = 16;
+  const int lane = threadIdx.x & 63, q = lane >> 4, lo = lane & 15;
+  float ah[3][4], ai[3][4];     // A operands: W_g[unit lo][input 4q + c]
+  gru_f32x4 ch[3], ci[3];       // biases in accumulator layout: unit 4q + r
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      ah[g][c] = w_hh[(g * E + lo) * E + 4 * q + c];
+      ai[g][c] = w_ih[(g * E + lo) * E + 4 * q + c];
+      ch[g][c] = b_hh[g * E + 4 * q + c];
+      ci[g][c] = b_ih[g * E + 4 * q + c];
+    }
+  }
+  const int64_t waves = ((int64_t)gridDim.x * kBlock) >> 6;
+  for (int64_t s0 = ((((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6)) * 16; s0 < batch; s0 += waves * 16) {
+    const int64_t smp = s0 + lo;
+    const bool live = smp < batch;
+    const int64_t sc = live ? smp : batch - 1;          // dead lanes compute on a copy of the last sample, store nothing
+    const float* xs = x + (sc * len) * ldx + 4 * q;
+    float* hs = hbuf + (sc * (len + 1)) * E + 4 * q;
+    gru_f32x4 h = {0.f, 0.f, 0.f, 0.f};
+    if (live) *reinterpret_cast<gru_f32x4*>(hs) = h;
+    // Memory traffic in blocks of four steps, ordered so that nothing is ever waited for right after it was issued
+    // (loads and stores share one in-order counter; PMC showed 25 % of the wave's life in s_waitcnt with the states
+    // stored step by step): at the end of a block first take over the x values requested a block ago, then store
+    // the block's four states, then request x of the block after next.
+    const gru_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    gru_f32x4 xc[4], xq[4], hout[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xc[u] = u < len ? *reinterpret_cast<const gru_f32x4*>(xs + (int64_t)u * ldx) : zero4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xq[u] = 4 + u < len ? *reinterpret_cast<const gru_f32x4*>(xs + (int64_t)(4 + u) * ldx) : zero4;
+    for (int t0 = 0; t0 < len; t0 += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u;
+        hout[u] = h;
+        if (t >= len) continue;
+        gru_f32x4 gi[3], gh[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          gi[g] = ci[g];
+          gh[g] = ch[g];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            gi[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[g][c], xc[u][c], gi[g], 0, 0, 0);
+            gh[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[g][c], h[c], gh[g], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float rg = gate_sigmoid(gi[0][r] + gh[0][r]);
+          const float zg = gate_sigmoid(gi[1][r] + gh[1][r]);
+          const float ng = gate_tanh(gi[2][r] + rg * gh[2][r]);
+          h[r] = (1.0f - zg) * ng + zg * h[r];
+        }
+        hout[u] = h;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xc[u] = xq[u];
+      if (live) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (t0 + u < len) *reinterpret_cast<gru_f32x4*>(hs + (int64_t)(t0 + u + 1) * E) = hout[u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        xq[u] = t0 + 8 + u < len ? *reinterpret_cast<const gru_f32x4*>(xs + (int64_t)(t0 + 8 + u) * ldx) : zero4;
+    }
+    if (last && live) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) last[smp * ldl + 4 * q + r] = h[r];
+    }
+  }
+}
+
+// Backward on the matrix cores, same ownership (lane (q, n): units 4q .. 4q+3 of sample n, sixteen samples per wave).
+// Per step: the forward products again (24 MFMAs); W_hh^T dgh and W_ih^T dgi with the gate gradients as B operands
+// straight out of their registers (24; the results land in the layout of dh and of the dX row to store); and the
+// weight gradients  dW_g[i][k] += sum_n dG_g[i][n] V[k][n]  -- a contraction over the SAMPLES, for which both operands
+// are needed unit-major (lane (q, u): unit u of samples 4q .. 4q+3): x_t / h_{t-1} are simply loaded a second time
+// in that order, the four gate-gradient tiles are transposed through a 5 KB strip of LDS private to the wave (24).
+// 72 matrix instructions of 32 cycles per step for sixteen samples, where the DPP kernel issues ~300 VALU
+// instructions, half of them at DPP rate, for four.
+constexpr int kGruTS = 20;   // row stride of a transposed tile: 16-byte aligned rows, two-way write conflicts at most
+
+__global__ void __launch_bounds__(kBlock)
+gru16_mfma_bwd_kernel(int64_t batch, int len, const float* __restrict__ x, int64_t ldx, const float* __restrict__ w_ih,
+                      const float* __restrict__ b_ih, const float* __restrict__ w_hh, const float* __restrict__ b_hh,
+                      const float* __restrict__ hbuf, const float* __restrict__ glast, int64_t ldgl,
+                      float* __restrict__ gx, int64_t ldgx, float* __restrict__ ws) {
+  constexpr int E = 16;
+  __shared__ __attribute__((aligned(16))) float s_t[kBlock / 64][4][E * kGruTS];   // per wave: dar, daz, dan, dhn tiles
+  __shared__ float s_part[kBlock / 64][kGruSlab];
+  const int lane = threadIdx.x & 63, q = lane >> 4, lo = lane & 15, wave = threadIdx.x >> 6;
+  float ah[3][4], ai[3][4];     // forward A operands: W_g[unit lo][input 4q + c]
+  float th[3][4], ti[3][4];     // transposed A operands: W_g[unit 4q + c][input lo]
+  gru_f32x4 ch[3], ci[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      ah[g][c] = w_hh[(g * E + lo) * E + 4 * q + c];
+      ai[g][c] = w_ih[(g * E + lo) * E + 4 * q + c];
+      th[g][c] = w_hh[(g * E + 4 * q + c) * E + lo];
+      ti[g][c] = w_ih[(g * E + 4 * q + c) * E + lo];
+      ch[g][c] = b_hh[g * E + 4 * q + c];
+      ci[g][c] = b_ih[g * E + 4 * q + c];
+    }
+  }
+  const gru_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  gru_f32x4 mi[3], mh[3];      // dW_ih / dW_hh gate blocks: register r = row 4q + r, column lo
+  gru_f32x4 sb[4];             // sums of dar, daz, dan, dhn over this lane's (sample, steps): units 4q + r
+#pragma unroll
+  for (int g = 0; g < 3; ++g) mi[g] = mh[g] = zero4;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) sb[g] = zero4;
+  float* tile = s_t[wave][0];
+  const int64_t waves = ((int64_t)gridDim.x * kBlock) >> 6;
+  for (int64_t s0 = ((((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6)) * 16; s0 < batch; s0 += waves * 16) {
+    const int64_t smp = s0 + lo;
+    const bool live = smp < batch;
+    const int64_t sc = live ? smp : batch - 1;
+    // a dead lane starts from a zero gradient: every gate gradient it forms is zero, it adds nothing anywhere
+    gru_f32x4 dh = zero4;
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh[r] = glast[smp * ldgl + 4 * q + r];
+    }
+    const float* xs = x + (sc * len) * ldx + 4 * q;                 // sample-major: units 4q .. 4q+3 of sample lo
+    const float* hs = hbuf + (sc * (len + 1)) * E + 4 * q;
+    // unit-major: unit lo of samples 4q + c (clamped like the others; dead samples meet zero gate gradients)
+    const float* xts[4];
+    const float* hts[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      int64_t sq = s0 + 4 * q + c;
+      if (sq >= batch) sq = batch - 1;
+      xts[c] = x + (sq * len) * ldx + lo;
+      hts[c] = hbuf + (sq * (len + 1)) * E + lo;
+    }
+    gru_f32x4 xv = zero4, hv = zero4, xt = zero4, ht = zero4;
+    if (len > 0) {
+      const int64_t t = len - 1;
+      xv = *reinterpret_cast<const gru_f32x4*>(xs + t * ldx);
+      hv = *reinterpret_cast<const gru_f32x4*>(hs + t * E);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        xt[c] = ctr_ldg(xts[c] + t * ldx);
+        ht[c] = ctr_ldg(hts[c] + t * E);
+      }
+    }
+    for (int t = len - 1; t >= 0; --t) {
+      // step t-1's operands, requested a step ahead
+      gru_f32x4 xvn = zero4, hvn = zero4, xtn = zero4, htn = zero4;
+      if (t > 0) {
+        const int64_t tp = t - 1;
+        xvn = *reinterpret_cast<const gru_f32x4*>(xs + tp * ldx);
+        hvn = *reinterpret_cast<const gru_f32x4*>(hs + tp * E);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          xtn[c] = ctr_ldg(xts[c] + tp * ldx);
+          htn[c] = ctr_ldg(hts[c] + tp * E);
+        }
+      }
+      gru_f32x4 gi[3], gh[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        gi[g] = ci[g];
+        gh[g] = ch[g];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          gi[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[g][c], xv[c], gi[g], 0, 0, 0);
+          gh[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[g][c], hv[c], gh[g], 0, 0, 0);
+        }
+      }
+      gru_f32x4 dar, daz, dan, dhn, zz;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float rg = gate_sigmoid(gi[0][r] + gh[0][r]);
+        const float zg = gate_sigmoid(gi[1][r] + gh[1][r]);
+        const float an = gh[2][r];
+        const float ng = gate_tanh(gi[2][r] + rg * an);
+        const float dz = dh[r] * (hv[r] - ng);
+        const float dn = dh[r] * (1.0f - zg);
+        dan[r] = dn * (1.0f - ng * ng);
+        dar[r] = dan[r] * an * rg * (1.0f - rg);
+        daz[r] = dz * zg * (1.0f - zg);
+        dhn[r] = dan[r] * rg;
+        zz[r] = zg;
+      }
+      sb[0] += dar; sb[1] += daz; sb[2] += dan; sb[3] += dhn;
+      // W^T d with the gate gradients as B operands as they are: dh_{t-1} - dh_t z and the dX row
+      gru_f32x4 tacc = zero4, xacc = zero4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(th[0][c], dar[c], tacc, 0, 0, 0);
+        xacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ti[0][c], dar[c], xacc, 0, 0, 0);
+        tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(th[1][c], daz[c], tacc, 0, 0, 0);
+        xacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ti[1][c], daz[c], xacc, 0, 0, 0);
+        tacc = __builtin_amdgcn_mfma_f32_16x16x4f32(th[2][c], dhn[c], tacc, 0, 0, 0);
+        xacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ti[2][c], dan[c], xacc, 0, 0, 0);
+      }
+      // the four gate-gradient tiles unit-major: tile[unit][sample]
+      {
+        const gru_f32x4* src[4] = {&dar, &daz, &dan, &dhn};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tile[k * (E * kGruTS) + (4 * q + r) * kGruTS + lo] = (*src[k])[r];
+      }
+      __builtin_amdgcn_wave_barrier();
+      gru_f32x4 dT[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) dT[k] = *reinterpret_cast<const gru_f32x4*>(tile + k * (E * kGruTS) + lo * kGruTS + 4 * q);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        mi[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT[0][c], xt[c], mi[0], 0, 0, 0);
+        mi[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT[1][c], xt[c], mi[1], 0, 0, 0);
+        mi[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT[2][c], xt[c], mi[2], 0, 0, 0);
+        mh[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT[0][c], ht[c], mh[0], 0, 0, 0);
+        mh[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT[1][c], ht[c], mh[1], 0, 0, 0);
+        mh[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(dT[3][c], ht[c], mh[2], 0, 0, 0);
+      }
+      if (live) *reinterpret_cast<gru_f32x4*>(gx + (smp * len + t) * ldgx + 4 * q) = xacc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh[r] = fmaf(dh[r], zz[r], tacc[r]);
+      xv = xvn; hv = hvn; xt = xtn; ht = htn;
+    }
+  }
+  // wave partial -> LDS slab [dW_ih 48x16 | dW_hh 48x16 | db_ih 48 | db_hh 48], the four waves summed in wave order
+  float* mine = s_part[wave];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      mine[(g * E + 4 * q + r) * E + lo] = mi[g][r];
+      mine[768 + (g * E + 4 * q + r) * E + lo] = mh[g][r];
+    }
+  // bias sums: over the sixteen samples of the wave (the lanes of a DPP row)
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = sb[k][r];
+      v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+      sb[k][r] = v;
+    }
+  if (lo == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      mine[1536 + 0 * E + 4 * q + r] = sb[0][r]; mine[1536 + 1 * E + 4 * q + r] = sb[1][r]; mine[1536 + 2 * E + 4 * q + r] = sb[2][r];
+      mine[1584 + 0 * E + 4 * q + r] = sb[0][r]; mine[1584 + 1 * E + 4 * q + r] = sb[1][r]; mine[1584 + 2 * E + 4 * q + r] = sb[3][r];
+    }
+  }
+  __syncthreads();
+  float* out = ws + (int64_t)blockIdx.x * kGruSlab;
+  for (int i = threadIdx.x; i < kGruSlab; i += kBlock)
+    out[i] = (s_part[0][i] + s_part[1][i]) + (s_part[2][i] + s_part[3][i]);
+}
+
 inline size_t fwd_lds(const GruGeom& g) {
   return sizeof(float) * (3 * g.dim * (g.dim + 1) + 2 * (kBlock / g.group) * g.dim);
 }
@@ -579,7 +866,17 @@ extern "C" int ctr_gru_fused_fwd(const float* x, int64_t ldx, const float* w_ih,
   if (batch == 0) return CTR_OK;
   CTR_REQUIRE(w_ih && b_ih && w_hh && b_hh && hbuf && (len == 0 || x) && ldx >= dim, CTR_EINVAL);
   CTR_REQUIRE(!last || ldl >= dim, CTR_EINVAL);
-  CTR_REQUIRE(dim == 16 && batch % 4 == 0, CTR_ELIMIT);
+  CTR_REQUIRE(dim == 16, CTR_ELIMIT);
+  static const bool dpp = [] { const char* e = getenv("CTR_GRU_DPP"); return e && e[0] == '1'; }();
+  if (!dpp && ldx % 4 == 0 && ctr_aligned16(x) && ctr_aligned16(hbuf)) {
+    // sixteen samples per wave on the matrix cores; any batch (a partial wave repeats its last sample)
+    int64_t grid = ctr_ceil_div(batch, (kBlock / 64) * 16);
+    if (grid > 256 * 4) grid = 256 * 4;
+    hipLaunchKernelGGL(gru16_mfma_fwd_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, batch, len, x,
+                       ldx, w_ih, b_ih, w_hh, b_hh, hbuf, last, ldl);
+    return ctr_launch_status();
+  }
+  CTR_REQUIRE(batch % 4 == 0, CTR_ELIMIT);
   GruGeom g;
   int rc = make_geom(batch, len, dim, &g);
   if (rc != CTR_OK) return rc;
@@ -596,15 +893,28 @@ extern "C" int ctr_gru_fused_bwd(const float* x, int64_t ldx, const float* w_ih,
   if (batch == 0) return CTR_OK;
   CTR_REQUIRE(w_ih && b_ih && w_hh && b_hh && hbuf && glast && gw_ih && gb_ih && gw_hh && gb_hh, CTR_EINVAL);
   CTR_REQUIRE((len == 0 || (x && gx)) && ldx >= dim && ldgx >= dim && ldgl >= dim, CTR_EINVAL);
-  CTR_REQUIRE(dim == 16 && batch % 4 == 0, CTR_ELIMIT);
+  CTR_REQUIRE(dim == 16, CTR_ELIMIT);
   if (len == 0) return CTR_OK;
-  // one wave per SIMD is what the ~330 registers of a lane allow: a grid of one workgroup per CU, each group
-  // walking batch / (256 * 16) samples
-  int64_t grid = ctr_ceil_div(batch, kBlock / 16);
-  if (grid > 256) grid = 256;
+  static const bool dpp = [] { const char* e = getenv("CTR_GRU_DPP"); return e && e[0] == '1'; }();
+  const bool mfma = !dpp && ldx % 4 == 0 && ldgx % 4 == 0 && ctr_aligned16(x) && ctr_aligned16(hbuf) && ctr_aligned16(gx);
+  CTR_REQUIRE(mfma || batch % 4 == 0, CTR_ELIMIT);
+  int64_t grid;
+  if (mfma) {
+    grid = ctr_ceil_div(batch, (kBlock / 64) * 16);   // sixteen samples per wave
+    if (grid > 256 * 2) grid = 256 * 2;
+  } else {
+    // one wave per SIMD is what the 280 registers of a lane allow: one workgroup per CU, each lane group walking
+    // batch / (256 * 16) samples
+    grid = ctr_ceil_div(batch, kBlock / 16);
+    if (grid > 256) grid = 256;
+  }
   CTR_REQUIRE(workspace && workspace_floats >= grid * kGruSlab, CTR_EINVAL);
-  hipLaunchKernelGGL(gru16_fused_bwd_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, batch, len, x,
-                     ldx, w_ih, b_ih, w_hh, b_hh, hbuf, glast, ldgl, gx, ldgx, workspace);
+  if (mfma)
+    hipLaunchKernelGGL(gru16_mfma_bwd_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, batch, len, x,
+                       ldx, w_ih, b_ih, w_hh, b_hh, hbuf, glast, ldgl, gx, ldgx, workspace);
+  else
+    hipLaunchKernelGGL(gru16_fused_bwd_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, batch, len, x,
+                       ldx, w_ih, b_ih, w_hh, b_hh, hbuf, glast, ldgl, gx, ldgx, workspace);
   int rc = ctr_launch_status();
   if (rc != CTR_OK) return rc;
   CtrSegments segs;

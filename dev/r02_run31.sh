@@ -1,0 +1,9 @@
+#!/bin/bash
+mkdir -p gpurun_out/r02
+timeout -k 10 500 python -m pytest tests/test_gpu_ops.py tests/test_gpu_models.py tests/test_gpu_fullsize.py -q -m gpu -k "gru or dien or DIEN" 2>&1 | tail -4
+timeout -k 10 300 python bench.py --workload dien --no-gather-leg --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/r02/bench_dien.json 2> gpurun_out/r02/bench_dien.err || tail -5 gpurun_out/r02/bench_dien.err
+python - <<PY
+import json
+d = json.load(open("gpurun_out/r02/bench_dien.json"))
+print("dien:", round(d["value"]/1e6, 2), "M/s ms", round(d["ms_per_step"], 4), {k: v["avg_us"] for k, v in list(d["kernels"].items())[:7]})
+PY
