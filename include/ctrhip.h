@@ -326,8 +326,9 @@ int ctr_gru_bwd(const float* gi, int64_t ldgi, const float* w_hh, const float* b
  * Forward writes hbuf / last as ctr_gru_fwd.  Backward recomputes the projection and leaves, instead of dgi / dgh,
  *   gx (batch*len, dim) = dgi W_ih,   gw_ih += dgi^T X,  gb_ih += sum dgi,  gw_hh += dgh^T H_prev,  gb_hh += sum dgh
  * (weight sums per workgroup in registers, fixed-order partials through the workspace: >= 256 * 1632 floats).
- * dim == 16 and batch % 4 == 0 only: CTR_ELIMIT otherwise with nothing enqueued -- use ctr_linear_fwd +
- * ctr_gru_fwd / ctr_gru_bwd + ctr_linear_bwd as above. */
+ * dim == 16 only (CTR_ELIMIT otherwise with nothing enqueued -- use ctr_linear_fwd + ctr_gru_fwd / ctr_gru_bwd +
+ * ctr_linear_bwd as above).  With 16-byte aligned x / hbuf / gx rows (ldx, ldgx multiples of 4) the recurrence runs on
+ * the matrix cores, sixteen samples per wave, for any batch; otherwise on DPP rows of four samples, batch % 4 == 0. */
 int ctr_gru_fused_fwd(const float* x, int64_t ldx, const float* w_ih, const float* b_ih, const float* w_hh,
                       const float* b_hh, int64_t batch, int len, int dim, float* hbuf, float* last /*nullable*/,
                       int64_t ldl, void* stream);

@@ -928,7 +928,7 @@ def test_linear_dx_masked_and_group_sums(ops, m, n, k, group):
     torch.testing.assert_close(gx2.cpu(), (gy.double() @ w.double()).float(), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("batch,length", [(64, 100), (8, 1), (12, 7), (260, 33)])
+@pytest.mark.parametrize("batch,length", [(64, 100), (8, 1), (12, 7), (260, 33), (5, 3), (17, 10), (1, 6)])
 def test_gru_with_the_input_projection_inside_matches_torch_gru(ops, batch, length):
     # DIEN interest evolution (model/dien.py:47,61: nn.GRU(E, E, batch_first=True), h0 = 0) at E = 16: forward
     # states, last state, input gradient and the four parameter gradients against torch autograd on the CPU
