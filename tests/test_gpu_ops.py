@@ -728,15 +728,6 @@ def test_gru_recurrence(ops, dim, length, batch):
     torch.testing.assert_close(g_b_hh.cpu(), leaves[3].grad.float(), **tol)
 
 
-def _close_except_relu_flips(got, want, rtol, atol, max_bad=2e-4):
-    """a ReLU unit whose pre-activation is within rounding of 0 can be on in fp32 and off
-    in fp64 (or the reverse): its row's gradient then legitimately differs.  Allow a
-    vanishing fraction of such elements, require everything else to agree."""
-    bad = ~torch.isclose(got, want, rtol=rtol, atol=atol)
-    frac = bad.float().mean().item()
-    assert frac <= max_bad, f"{bad.sum().item()} of {bad.numel()} elements differ ({frac:.2e})"
-
-
 FUSED_STACKS = [
     # (m, dims, activations)  dims[0] = input width
     (65536, [128, 64, 32, 16, 8, 64], [1, 1, 1, 1, 0]),     # NeuralCF tower at BASELINE configs[1]
