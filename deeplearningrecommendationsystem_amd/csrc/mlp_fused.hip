@@ -817,6 +817,29 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
                     t0 < tiles);
     if (gvec) pre_issue<true, FULLM>(gpre, gy, ldgy, t0 * 32, m, nl, div_last, lane0, t0 < tiles);
   }
+  // fused head backward: the tile's head inputs (gprob, prob, the last activations, the 64 extra columns of this
+  // lane's row) are requested a tile ahead -- loaded at the top of the tile they were an exposed memory latency per
+  // tile in a kernel whose waves see two tiles
+  float hp_g = 0.0f, hp_p = 0.0f;
+  float4 hp_y = make_float4(0.f, 0.f, 0.f, 0.f), hp_x[8];
+  auto head_fetch = [&](int64_t tl) {
+    const int64_t row = tl * 32 + (lane0 & 31);
+    const bool ok = tl < tiles && (FULLM || row < m);
+    const int hh = lane0 >> 5;
+    hp_g = hp_p = 0.0f;
+    hp_y = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hp_x[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+      hp_g = hb.gprob[row * hb.ldgp];
+      hp_p = hb.prob[row * hb.ldp];
+      hp_y = *reinterpret_cast<const float4*>(d.l[last].y + row * d.l[last].ldy + 4 * hh);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)   // half = i >> 2: columns 32 hh + 16 half + 4 (i & 3)
+        hp_x[i] = *reinterpret_cast<const float4*>(hb.xe + row * hb.ldxe + 32 * hh + 16 * (i >> 2) + 4 * (i & 3));
+    }
+  };
+  if constexpr (HEADB) head_fetch((int64_t)blockIdx.x * kWaves + wave);
   for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < tiles; tile += tstride) {
     const int64_t row0 = tile * 32;
     // fixed shape: every lane-derived LDS / global offset of the unrolled stack is loop
@@ -834,14 +857,19 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
       // lane r ends up with column (r & 15) of each 16-column group, summed over the 32 rows
       const int64_t row = row0 + r;
       const bool ok = FULLM || row < m;
-      float gz = 0.0f;
-      if (ok) gz = hb.gprob[row * hb.ldgp] * ctr_act_grad(hb.prob[row * hb.ldp], hb.act);
+      const float gz = hp_g * ctr_act_grad(hp_p, hb.act);   // rows past m were fetched as zeros
+      const float4 yv = hp_y;
+      {
+        // the tower's gY tile with the last layer's activation derivative folded in (its outputs are right here):
+        // no separate masking pass over Y
+        const int act_l = S::kFixed ? S::ACT[S::kFixed ? S::kLayers - 1 : 0] : d.l[last].act;
+        const float yq[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) tp[r * sa + 4 * h + q] = gz * s_hwb[kHeadBwdP + 4 * h + q];
+        for (int q = 0; q < 4; ++q)
+          tp[r * sa + 4 * h + q] = gz * s_hwb[kHeadBwdP + 4 * h + q] * ctr_act_grad(yq[q], act_l);
+      }
       if (h == 0) hc_sum += gz;
       {
-        float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) yv = *reinterpret_cast<const float4*>(d.l[last].y + row * d.l[last].ldy + 4 * h);
         float pr[4] = {gz * yv.x, gz * yv.y, gz * yv.z, gz * yv.w};
         xpose_stage<2>(pr, r & 2, 2);
         xpose_stage<1>(pr, r & 1, 1);
@@ -857,13 +885,11 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
         float pr[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 xv = hp_x[4 * half + i];
           const float4 wv = *reinterpret_cast<const float4*>(s_hwb + c0 + 4 * i);
-          if (ok) {
-            xv = *reinterpret_cast<const float4*>(hb.xe + row * hb.ldxe + c0 + 4 * i);
+          if (ok)
             *reinterpret_cast<float4*>(hb.gxe + row * hb.ldgxe + c0 + 4 * i) =
                 make_float4(gz * wv.x, gz * wv.y, gz * wv.z, gz * wv.w);
-          }
           pr[4 * i + 0] = gz * xv.x; pr[4 * i + 1] = gz * xv.y; pr[4 * i + 2] = gz * xv.z; pr[4 * i + 3] = gz * xv.w;
         }
         xpose_stage<8>(pr, r & 8, 8);
@@ -872,6 +898,7 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
         xpose_stage<1>(pr, r & 1, 1);
         hx_sum[half] += pr[0] + __shfl_xor(pr[0], 16, 64);  // column c0 + (r & 15)
       }
+      head_fetch(tile + tstride);   // everything of this tile is consumed: the registers take the next tile's
     } else if (kPre && gvec) {
       pre_commit<true>(gpre, tp, sa, nl, div_last, lane);
     } else {
@@ -881,7 +908,7 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
     {
       // gZ = gY * act'(Y) of the last layer, in place (rows past m stay zero)
       const int act_last = S::kFixed ? S::ACT[S::kFixed ? S::kLayers - 1 : 0] : d.l[last].act;
-      if (act_last != CTR_ACT_NONE) {
+      if (!HEADB && act_last != CTR_ACT_NONE) {   // (the fused head wrote the tile already masked)
         tile_mask<8, S::kFixed, FULLM>(tp, sa, d.l[last].y, d.l[last].ldy, row0, m, nl, div_last, act_last, lane);
         __builtin_amdgcn_wave_barrier();
       }
