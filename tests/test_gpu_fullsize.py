@@ -167,3 +167,43 @@ def test_n_field_models_config3_as_worded_full_size_against_oracle(name):
         want = grads_ref[k]
         floor = 1e-6 + 1e-5 * float(want.abs().max())
         torch.testing.assert_close(p.grad.cpu(), want, rtol=1e-4, atol=floor, msg=lambda s, k=k: f"grad {k}: {s}")
+
+
+def test_gru_config5_full_size_matrix_core_kernels_against_the_gemm_decomposition():
+    # DIEN's interest evolution at cfg5 (32768 x 100 steps, E = 16): the recurrence with the input projection inside
+    # (sixteen samples per wave on the matrix cores) against the independent decomposition the library also has --
+    # gi as a GEMM, the DPP recurrence kernels, dX / dW_ih / dW_hh as GEMMs over dgi / dgh (model/dien.py:47,61)
+    from deeplearningrecommendationsystem_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(5)
+    batch, length, dim = 32768, 100, 16
+    x = torch.randn(batch * length, dim, device=DEV, generator=g) * 0.5
+    w_ih, w_hh = (torch.randn(3 * dim, dim, device=DEV, generator=g) * 0.3 for _ in range(2))
+    b_ih, b_hh = (torch.randn(3 * dim, device=DEV, generator=g) * 0.1 for _ in range(2))
+    glast = torch.randn(batch, dim, device=DEV, generator=g)
+    # fused
+    hbuf = torch.empty(batch * (length + 1), dim, device=DEV)
+    last = torch.empty(batch, dim, device=DEV)
+    assert ops.gru_fused_fwd(x, w_ih, b_ih, w_hh, b_hh, batch, length, dim, hbuf, last)
+    gx = torch.empty_like(x)
+    gw_ih, gw_hh, gb_ih, gb_hh = (torch.zeros_like(t) for t in (w_ih, w_hh, b_ih, b_hh))
+    ops.gru_fused_bwd(x, w_ih, b_ih, w_hh, b_hh, hbuf, batch, length, dim, glast, gx, gw_ih, gb_ih, gw_hh, gb_hh)
+    # decomposition
+    gi = ops.linear_fwd(x, w_ih, b_ih)
+    hbuf2 = torch.empty_like(hbuf)
+    last2 = torch.empty_like(last)
+    ops.gru_fwd(gi, w_hh, b_hh, batch, length, dim, hbuf2, last2)
+    torch.testing.assert_close(hbuf, hbuf2, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(last, last2, rtol=1e-5, atol=1e-5)
+    assert float(hbuf.std()) > 0.05                      # not a degenerate recurrence
+    dgi = torch.empty(batch * length, 3 * dim, device=DEV)
+    dgh = torch.empty(batch * (length + 1), 3 * dim, device=DEV)
+    ops.gru_bwd(gi, w_hh, b_hh, hbuf2, batch, length, dim, glast, dgi, dgh)
+    gx2 = torch.empty_like(x)
+    rw_ih, rw_hh, rb_ih, rb_hh = (torch.zeros_like(t) for t in (w_ih, w_hh, b_ih, b_hh))
+    ops.linear_bwd(x, w_ih, None, dgi, ops.ACT_NONE, gx2, rw_ih, rb_ih)
+    rows = batch * (length + 1) - 1
+    ops.linear_bwd(hbuf2[:rows], w_hh, None, dgh[1:], ops.ACT_NONE, None, rw_hh, rb_hh)
+    torch.testing.assert_close(gx, gx2, rtol=1e-4, atol=1e-5)
+    scale = float(rw_ih.abs().max())
+    for got, want in ((gw_ih, rw_ih), (gw_hh, rw_hh), (gb_ih, rb_ih), (gb_hh, rb_hh)):
+        torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5 * max(1.0, scale))
