@@ -207,3 +207,32 @@ def test_gru_config5_full_size_matrix_core_kernels_against_the_gemm_decompositio
     scale = float(rw_ih.abs().max())
     for got, want in ((gw_ih, rw_ih), (gw_hh, rw_hh), (gb_ih, rb_ih), (gb_hh, rb_hh)):
         torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5 * max(1.0, scale))
+
+
+def test_din_history_gradient_config5_full_size_scatter_from_the_gemm_against_two_passes():
+    # DIN cfg5 (1e7 x 64 table, 32768 x 100 positions, a quarter of them the padding id): the layer-1 input gradient
+    # added to the table gradient from the dX GEMM's epilogue (ctr_linear_dx_scatter) against the same gradient
+    # written to memory by ctr_linear_bwd and scattered by ctr_din_scatter_bwd (model/din.py:35-44 backward)
+    from deeplearningrecommendationsystem_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(11)
+    batch, length, dim, n1, vocab = 32768, 100, 64, 128, 10_000_000
+    m = batch * length
+    w = torch.randn(n1, dim, device=DEV, generator=g) / n1 ** 0.5
+    gz = torch.randn(m, n1, device=DEV, generator=g) * 0.1
+    attn = torch.rand(batch, length, device=DEV, generator=g)
+    gpool = torch.randn(batch, 2 * dim, device=DEV, generator=g)[:, :dim]
+    hist = torch.randint(1, vocab, (batch, length), device=DEV, generator=g)
+    hist[torch.rand(batch, length, device=DEV, generator=g) < 0.25] = 0
+    hist[0, 0], hist[0, 1] = vocab - 1, 1
+    fused = torch.zeros(vocab, dim, device=DEV)
+    ops.linear_dx_scatter(w, gz, hist.reshape(-1), attn.reshape(-1), gpool, length, fused)
+    gh = torch.empty(m, dim, device=DEV)
+    ops.linear_bwd(torch.empty(m, dim, device=DEV), w, None, gz, ops.ACT_NONE, gh, None, None)
+    two = torch.zeros(vocab, dim, device=DEV)
+    ops.din_scatter_bwd(hist, vocab, dim, gh, attn, gpool, True, two)
+    # the padding row sums ~800 k positions in two different orders; every other row a handful
+    torch.testing.assert_close(fused[0], two[0], rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(fused[1:], two[1:], rtol=1e-4, atol=1e-5)
+    touched = int((two.abs().sum(1) > 0).sum())
+    assert touched == int(torch.unique(hist).numel())
+    assert float(fused[vocab - 1].abs().sum()) > 0
