@@ -480,6 +480,24 @@ mlp_fwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
       const float* xin = (li & 1) ? tb : ta;
       float* xout = (li & 1) ? ta : tb;
       const int sin = (li & 1) ? sb : sa, sout = (li & 1) ? sa : sb;
+      if (S::kFixed && !HEAD && li == nlayers - 1 && L.n == 1 && L.k % 8 == 0) {
+        // a single-unit last layer of a pinned stack (DIEN's attention score, model/dien.py:13-19) is a dot product
+        // per row: on the matrix cores it occupied a whole 32-column tile (16 of the 80 MFMAs of a tile) for one
+        // useful column.  Lane (r, h) takes half of row r's inputs, the halves meet by shuffle.
+        const int kh = L.k / 2;
+        const float* xr = xin + r * sin + kh * h;
+        const float* wr = wl + kh * h;
+        float acc = 0.0f;
+        for (int v = 0; v < kh; v += 4) {
+          const float4 xv = *reinterpret_cast<const float4*>(xr + v);
+          const float4 wv = *reinterpret_cast<const float4*>(wr + v);
+          acc = fmaf(xv.x, wv.x, acc); acc = fmaf(xv.y, wv.y, acc); acc = fmaf(xv.z, wv.z, acc); acc = fmaf(xv.w, wv.w, acc);
+        }
+        acc += __shfl_xor(acc, 32, 64);
+        if (h == 0 && row0 + r < m) L.y[(row0 + r) * L.ldy] = ctr_act(acc + s_w[L.b_off], L.act);
+        __builtin_amdgcn_wave_barrier();
+        continue;
+      }
 #pragma unroll
       for (int ct = 0; ct < nct; ++ct) {
         floatx16 a, a1;
