@@ -110,6 +110,10 @@ struct CtrSegments {
 };
 int ctr_reduce_segments(const float* ws, int parts, int64_t stride, const CtrSegments& segs, hipStream_t st);
 
+// mlp_mfma16.hip: the pinned NeuralCF tower + 64-column head with activations in matrix-core operand layout
+// (CTR_ELIMIT: shape / alignment not taken, nothing enqueued)
+int ctr_ncf16_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, const ctr_mlp_head_t* head,
+                  hipStream_t st);
 // internal (not part of the C ABI): single-output-unit linear layer, linear_n1.hip
 bool ctr_n1_supported(int k);
 // embed_sorted.hip: sorted segmented-reduce backward for small tables (see there)

@@ -1688,6 +1688,13 @@ static int mlp_fwd_impl(const float* x, int64_t ldx, int64_t m, const ctr_mlp_la
     CTR_REQUIRE(head->p == 0 || (ctr_aligned16(head->x) && head->ldx % 4 == 0), CTR_EALIGN);
     hd = HeadDesc{head->x, head->ldx, head->p, head->w, head->c, head->out, head->ldout, head->act};
     if (matches<NcfTowerShape, false>(layers, nlayers, b.d)) {
+      // activations in matrix-core operand layout, sixteen samples per wave (mlp_mfma16.hip); CTR_MLP_16=0 keeps
+      // the tile-walking kernels below
+      static const bool m16 = [] { const char* e = getenv("CTR_MLP_16"); return !(e && e[0] == '0'); }();
+      if (m16) {
+        rc = ctr_ncf16_fwd(x, ldx, m, layers, head, st);
+        if (rc != CTR_ELIMIT) return rc;
+      }
       static const bool four = [] { const char* e = getenv("CTR_MLP_FWD_WAVES"); return e && e[0] == '4'; }();
       if (!four) {  // two waves per SIMD (see mlp_fwd_direct_kernel); CTR_MLP_FWD_WAVES=4 keeps the A/B alive
         constexpr size_t bytes = DirectLayout<NcfTowerShape>::lds_bytes();
