@@ -114,6 +114,9 @@ int ctr_reduce_segments(const float* ws, int parts, int64_t stride, const CtrSeg
 // (CTR_ELIMIT: shape / alignment not taken, nothing enqueued)
 int ctr_ncf16_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, const ctr_mlp_head_t* head,
                   hipStream_t st);
+int ctr_ncf16_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, const ctr_mlp_head_grad_t* hg,
+                  float* gx, int64_t ldgx, float* workspace, int64_t workspace_floats, int* grid_out, hipStream_t st);
+int ctr_ncf16_slab_floats();
 // internal (not part of the C ABI): single-output-unit linear layer, linear_n1.hip
 bool ctr_n1_supported(int k);
 // embed_sorted.hip: sorted segmented-reduce backward for small tables (see there)

@@ -1836,6 +1836,20 @@ extern "C" int ctr_mlp_head_bwd(const float* x, int64_t ldx, int64_t m, const ct
   const int64_t slab = b.slab + kHeadBwdSums;
   CTR_REQUIRE(workspace_floats >= grid * slab, CTR_ELIMIT);
   hipStream_t st = (hipStream_t)stream;
+  // activations and gradients in matrix-core operand layout, sixteen samples per wave (mlp_mfma16.hip; same slab
+  // layout); CTR_MLP_16=0 keeps the tile-walking kernels below
+  static const bool m16 = [] { const char* e = getenv("CTR_MLP_16"); return !(e && e[0] == '0'); }();
+  bool done16 = false;
+  if (m16 && gx && slab == ctr_ncf16_slab_floats()) {
+    int g16 = 0;
+    rc = ctr_ncf16_bwd(x, ldx, m, layers, hg, gx, ldgx, workspace, workspace_floats, &g16, st);
+    if (rc == CTR_OK) {
+      grid = g16;
+      done16 = true;
+    } else if (rc != CTR_ELIMIT) {
+      return rc;
+    }
+  }
   const HeadBwdDesc hb{hg->gprob, hg->ldgprob, hg->prob, hg->ldprob, hg->x, hg->ldx, hg->w, hg->gx, hg->ldgx, hg->act};
   // CTR_MLP_PAIR=1 selects the two-waves-per-tile kernel (A/B switch).  Measured on MI355X, batch 65536 (rocprofv3,
   // profiles/r02_mlp_pair_ab.txt): 73.1 us against 72.3 us for the one-wave-per-tile kernel -- occupancy 2, 201
@@ -1850,7 +1864,9 @@ extern "C" int ctr_mlp_head_bwd(const float* x, int64_t ldx, int64_t m, const ct
     const char* e = getenv("CTR_MLP_PAIR");
     return e && e[0] == '1';
   }();
-  if (pair_on) {
+  if (done16) {
+    // launched above
+  } else if (pair_on) {
     // two waves per row tile, eight per workgroup (same tiles per workgroup, same slab layout)
     const size_t lds_bytes = b.lds_bytes + sizeof(float) * (size_t)(kPairWaves - kWaves) * b.d.nsum;
     CTR_REQUIRE(lds_bytes + sizeof(StackDesc) <= 160 * 1024, CTR_ELIMIT);

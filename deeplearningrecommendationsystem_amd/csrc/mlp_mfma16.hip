@@ -198,7 +198,430 @@ ncf16_fwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
   }
 }
 
+// ------------------------------------------------------------------ backward
+struct HeadBwd {
+  const float* gprob; int64_t ldgp;
+  const float* prob; int64_t ldp;
+  const float* xe; int64_t ldxe;     // the 64 extra columns
+  const float* w;                    // 64 + 8 head weights
+  float* gxe; int64_t ldgxe;         // gradient of the extra columns (=)
+  int act;
+};
+
+constexpr int kTS = 20;                                   // row stride of a transposition tile (16-byte aligned rows)
+constexpr int kStrip = 4 * 16 * kTS;                      // four tiles per wave
+constexpr int kBwdMain = kWFloats + kWaves * kStrip;      // floats: transposed weights, then the waves' strips
+constexpr int slab_w(int l) {                             // float offset of layer l's dW inside a slab
+  int o = 0;
+  for (int i = 0; i < l; ++i) o += kN[i] * kK[i] + kN[i];
+  return o;
+}
+constexpr int kSlabHead = slab_w(kL);                     // 11000
+constexpr int kSlab = kSlabHead + kHeadW + 1;             // 11073
+// at the end three waves park their sums side by side (the weights are dead), the fourth adds into the first copy
+constexpr int kBwdLds = 3 * kSlab > kBwdMain ? 3 * kSlab : kBwdMain;
+
+// transposed A operands: s_wt[wa_off(l) + ((j*B + b)*64 + lane)*4 + c] = W_l[16b + 4(lane/16) + c][16j + lane%16]
+__device__ __forceinline__ void stage_transposed_weights(float* s_wt, const Tower& T) {
+  constexpr int kUnits = kWFloats / 4;
+  constexpr int kPer = (kUnits + kThreads - 1) / kThreads;
+  f32x4 v[kPer];
+  int dst[kPer];
+#pragma unroll
+  for (int i = 0; i < kPer; ++i) {
+    int u = threadIdx.x + i * kThreads;
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dst[i] = -1;
+    if (u < kUnits) {
+      int l = 0;
+#pragma unroll
+      for (int t = 0; t < kL - 1; ++t)
+        if (u >= wa_off(t + 1) / 4) l = t + 1;
+      u -= wa_off(l) / 4;
+      const int K4 = kK[l] / 4, B = blocks(kN[l]);
+      const int unit = u / K4, t4 = u - unit * K4;        // W_l[unit][4 t4 .. 4 t4 + 3]
+      const int b = unit >> 4, qq = (unit >> 2) & 3, c = unit & 3, j = t4 >> 2, lo0 = (4 * t4) & 15;
+      dst[i] = wa_off(l) + ((j * B + b) * 64 + qq * 16 + lo0) * 4 + c;   // + 4 per consecutive input
+      if (unit < kN[l]) v[i] = ldg4(T.w[l] + (int64_t)unit * kK[l] + 4 * t4);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kPer; ++i)
+    if (dst[i] >= 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s_wt[dst[i] + 4 * e] = v[i][e];
+    }
+}
+
+// sum over the 16 lanes of a DPP row, result in every lane
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x122, 0xF, 0xF, true));  // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x121, 0xF, 0xF, true));  // row_ror:1
+  return v;
+}
+
+__device__ __forceinline__ f32x4 relu_mask(const f32x4& g, const f32x4& y) {
+  f32x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = y[r] > 0.0f ? g[r] : 0.0f;
+  return o;
+}
+
+// sample-major block (lane (q, n): units 4q + r of sample n) -> unit-major (lane (q, u): unit u, samples 4q + c)
+__device__ __forceinline__ f32x4 transpose_block(float* tile, int q, int lo, const f32x4& v) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tile[(4 * q + r) * kTS + lo] = v[r];
+  __builtin_amdgcn_wave_barrier();
+  const f32x4 t = *reinterpret_cast<const f32x4*>(tile + lo * kTS + 4 * q);
+  __builtin_amdgcn_wave_barrier();
+  return t;
+}
+
+template <int NB>   // NB blocks at once: all writes, one barrier, all reads
+__device__ __forceinline__ void transpose_blocks(float* strip, int q, int lo, const f32x4 (&v)[NB], f32x4 (&t)[NB]) {
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) strip[b * 16 * kTS + (4 * q + r) * kTS + lo] = v[b][r];
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int b = 0; b < NB; ++b) t[b] = *reinterpret_cast<const f32x4*>(strip + b * 16 * kTS + lo * kTS + 4 * q);
+  __builtin_amdgcn_wave_barrier();
+}
+
+// two dX^T blocks of layer L at once (independent accumulator chains)
+template <int L, int NB>
+__device__ __forceinline__ void dx_block2(const float* s_wt, int lane, int j, const f32x4 (&gz)[NB], f32x4& o0, f32x4& o1) {
+  constexpr int B = blocks(kN[L]);
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+  const float* wb0 = s_wt + wa_off(L) + ((j * B) * 64 + lane) * 4;
+  const float* wb1 = wb0 + B * 256;
+  f32x4 w0 = *reinterpret_cast<const f32x4*>(wb0), w1 = *reinterpret_cast<const f32x4*>(wb1);
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const f32x4 wa = w0, wc = w1;
+    if (b + 1 < B) {
+      w0 = *reinterpret_cast<const f32x4*>(wb0 + (b + 1) * 256);
+      w1 = *reinterpret_cast<const f32x4*>(wb1 + (b + 1) * 256);
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c], gz[b][c], a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[c], gz[b][c], a1, 0, 0, 0);
+    }
+  }
+  o0 = a0;
+  o1 = a1;
+}
+
+// dX^T block(s) of layer L: out[j] = sum_b sum_c WT_L[j][b][lane][c] (x) gz[b][c]   (out in the layout of gz)
+template <int L, int NB>
+__device__ __forceinline__ f32x4 dx_block(const float* s_wt, int lane, int j, const f32x4 (&gz)[NB]) {
+  constexpr int B = blocks(kN[L]);
+  static_assert(B == NB, "gradient blocks");
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* wbase = s_wt + wa_off(L) + ((j * B) * 64 + lane) * 4;
+  f32x4 w0 = *reinterpret_cast<const f32x4*>(wbase);
+#pragma unroll
+  for (int b = 0; b < B; ++b) {
+    const f32x4 wa = w0;
+    if (b + 1 < B) w0 = *reinterpret_cast<const f32x4*>(wbase + (b + 1) * 256);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c], gz[b][c], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+__global__ void __launch_bounds__(kThreads)
+ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_t m, const HeadBwd H,
+                 float* __restrict__ gx, int64_t ldgx, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ __attribute__((aligned(16))) float s_hw[kHeadW];
+  float* s_wt = lds;
+  const int lane = threadIdx.x & 63, q = lane >> 4, lo = lane & 15, wave = threadIdx.x >> 6;
+  float* strip = lds + kWFloats + wave * kStrip;
+  const int64_t groups = (m + 15) / 16;
+  const int64_t wave0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * kThreads) >> 6;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // ---- operands of a sample group, all requested together (a group ahead of their use)
+  float gp = 0.0f, pb = 0.0f;
+  f32x4 y4d = zero4, xe[4], y3d = zero4, y2d[2], y1d[4];     // sample-major: units 4q + r (+16 per block) of sample lo
+  f32x4 y3t = zero4, y2t[2], y1t[4], x0t[8];                 // unit-major: unit lo (+16 per block) of samples 4q + c
+  // Requested per layer, for the NEXT group, as soon as this group has consumed the registers: every load then has
+  // most of a group's time (~10 us) to land.  (All 72 requested together in front of dX_0 left 37 % of the wave's life
+  // in s_waitcnt: every wave of the chip issued its burst at the same moment.)
+  auto rows_of = [&](int64_t g, int64_t& rc, bool& live, int64_t (&rt)[4]) {
+    const int64_t row = g * 16 + lo;
+    live = g < groups && row < m;
+    rc = live ? row : (m - 1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      rt[c] = g * 16 + 4 * q + c;
+      if (g >= groups || rt[c] >= m) rt[c] = m - 1;          // meets a zero gradient
+    }
+  };
+  auto fetch_head = [&](int64_t g) {
+    int64_t rc, rt[4]; bool live;
+    rows_of(g, rc, live, rt);
+    gp = live ? H.gprob[rc * H.ldgp] : 0.0f;                 // a dead lane's gz is zero: it adds nothing anywhere
+    pb = H.prob[rc * H.ldp];
+    y4d = q < 2 ? ldg4(T.y[3] + rc * T.ldy[3] + 4 * q) : zero4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xe[i] = ldg4(H.xe + rc * H.ldxe + 16 * q + 4 * i);
+  };
+  auto fetch_l3 = [&](int64_t g) {
+    int64_t rc, rt[4]; bool live;
+    rows_of(g, rc, live, rt);
+    y3d = ldg4(T.y[2] + rc * T.ldy[2] + 4 * q);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) y3t[c] = T.y[2][rt[c] * T.ldy[2] + lo];
+  };
+  auto fetch_l2 = [&](int64_t g) {
+    int64_t rc, rt[4]; bool live;
+    rows_of(g, rc, live, rt);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      y2d[b] = ldg4(T.y[1] + rc * T.ldy[1] + 16 * b + 4 * q);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) y2t[b][c] = T.y[1][rt[c] * T.ldy[1] + 16 * b + lo];
+    }
+  };
+  auto fetch_l1 = [&](int64_t g) {
+    int64_t rc, rt[4]; bool live;
+    rows_of(g, rc, live, rt);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      y1d[b] = ldg4(T.y[0] + rc * T.ldy[0] + 16 * b + 4 * q);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) y1t[b][c] = T.y[0][rt[c] * T.ldy[0] + 16 * b + lo];
+    }
+  };
+  auto fetch_l0 = [&](int64_t g) {
+    int64_t rc, rt[4]; bool live;
+    rows_of(g, rc, live, rt);
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) x0t[b][c] = x[rt[c] * ldx + 16 * b + lo];
+  };
+  fetch_head(wave0); fetch_l3(wave0); fetch_l2(wave0); fetch_l1(wave0); fetch_l0(wave0);
+  stage_transposed_weights(s_wt, T);
+  for (int i = threadIdx.x; i < kHeadW; i += blockDim.x) s_hw[i] = H.w[i];
+  __syncthreads();
+
+  // ---- what a lane sums over every group it walks
+  f32x4 dw0[4][8], dw1[2][4], dw2[2], dw3;                   // dW blocks: register r = row 4q + r, column lo
+  f32x4 sb0[4], sb1[2], sb2, sb3;                            // bias sums of this lane's sample: units 4q + r
+  f32x4 hy = zero4, hx[4];
+  float hc = 0.0f;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    sb0[b] = zero4;
+    hx[b] = zero4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dw0[b][j] = zero4;
+  }
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    sb1[b] = zero4;
+    dw2[b] = zero4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dw1[b][j] = zero4;
+  }
+  sb2 = sb3 = dw3 = zero4;
+
+  for (int64_t g = wave0; g < groups; g += nwaves) {
+    const int64_t row = g * 16 + lo;
+    const bool live = row < m;
+    // ---- head: gz, the extra columns' gradient, the head's sums, the tower's (masked) gY
+    const float gz = gp * ctr_act_grad(pb, H.act);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(s_hw + 16 * q + 4 * i);
+      if (live) stg4(H.gxe + row * H.ldgxe + 16 * q + 4 * i, gz * wv);
+      hx[i] += gz * xe[i];
+    }
+    if (q == 0) hc += gz;
+    f32x4 gz3[1];
+    {
+      const f32x4 wv = q < 2 ? *reinterpret_cast<const f32x4*>(s_hw + kP + 4 * q) : zero4;
+      hy += gz * y4d;                                         // (y4d is zero for q >= 2)
+      gz3[0] = relu_mask(gz * wv, y4d);
+    }
+    fetch_head(g + nwaves);
+    // ---- layer 3 (16 -> 8)
+    sb3 += gz3[0];
+    {
+      const f32x4 tg = transpose_block(strip, q, lo, gz3[0]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dw3 = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[c], y3t[c], dw3, 0, 0, 0);
+    }
+    f32x4 gz2[1];
+    gz2[0] = relu_mask(dx_block<3, 1>(s_wt, lane, 0, gz3), y3d);
+    fetch_l3(g + nwaves);
+    // ---- layer 2 (32 -> 16)
+    sb2 += gz2[0];
+    {
+      const f32x4 tg = transpose_block(strip, q, lo, gz2[0]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dw2[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[c], y2t[j][c], dw2[j], 0, 0, 0);
+    }
+    f32x4 gz1[2];
+    {
+      f32x4 d0, d1;
+      dx_block2<2, 1>(s_wt, lane, 0, gz2, d0, d1);
+      gz1[0] = relu_mask(d0, y2d[0]);
+      gz1[1] = relu_mask(d1, y2d[1]);
+    }
+    fetch_l2(g + nwaves);
+    // ---- layer 1 (64 -> 32)
+    {
+      f32x4 tg[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) sb1[b] += gz1[b];
+      transpose_blocks<2>(strip, q, lo, gz1, tg);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            dw1[b][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[b][c], y1t[j][c], dw1[b][j], 0, 0, 0);
+    }
+    f32x4 gz0[4];
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+      f32x4 d0, d1;
+      dx_block2<1, 2>(s_wt, lane, j, gz1, d0, d1);
+      gz0[j] = relu_mask(d0, y1d[j]);
+      gz0[j + 1] = relu_mask(d1, y1d[j + 1]);
+    }
+    fetch_l1(g + nwaves);
+    // ---- layer 0 (128 -> 64)
+    {
+      f32x4 tg[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) sb0[b] += gz0[b];
+      transpose_blocks<4>(strip, q, lo, gz0, tg);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            dw0[b][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[b][c], x0t[j][c], dw0[b][j], 0, 0, 0);
+    }
+    fetch_l0(g + nwaves);   // x of the next group lands under dX_0 and the next group's upper layers
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      f32x4 d0, d1;
+      dx_block2<0, 4>(s_wt, lane, j, gz0, d0, d1);
+      if (live) {
+        stg4(gx + row * ldgx + 16 * j + 4 * q, d0);
+        stg4(gx + row * ldgx + 16 * (j + 1) + 4 * q, d1);
+      }
+    }
+  }
+
+  // ---- the workgroup's partial (the weights are dead): waves 0..2 store their sums into three copies of the slab at
+  // once, wave 3 then adds into the first copy, and the copies are summed on the way out.  (Four waves taking turns
+  // on one copy were 4 x 690 dependent LDS read-modify-writes per lane: a third of the kernel.)
+  __syncthreads();
+  for (int round = 0; round < 2; ++round) {
+    if ((round == 0) == (wave < 3)) {
+      float* slab = lds + (wave < 3 ? wave : 0) * kSlab;
+      const bool add = wave == 3;
+      auto put = [&](int idx, float v) { slab[idx] = add ? slab[idx] + v : v; };
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) put(slab_w(0) + (16 * b + 4 * q + r) * kK[0] + 16 * j + lo, dw0[b][j][r]);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) put(slab_w(1) + (16 * b + 4 * q + r) * kK[1] + 16 * j + lo, dw1[b][j][r]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) put(slab_w(2) + (4 * q + r) * kK[2] + 16 * j + lo, dw2[j][r]);
+      if (q < 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) put(slab_w(3) + (4 * q + r) * kK[3] + lo, dw3[r]);
+      }
+      // sums over the samples: the sixteen lanes of a DPP row
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const float v = row_sum16(sb0[b][r]);
+          if (lo == 0) put(slab_w(0) + kN[0] * kK[0] + 16 * b + 4 * q + r, v);
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const float v = row_sum16(sb1[b][r]);
+          if (lo == 0) put(slab_w(1) + kN[1] * kK[1] + 16 * b + 4 * q + r, v);
+        }
+        const float v2 = row_sum16(sb2[r]), v3 = row_sum16(sb3[r]), vy = row_sum16(hy[r]);
+        if (lo == 0) put(slab_w(2) + kN[2] * kK[2] + 4 * q + r, v2);
+        if (lo == 0 && q < 2) {
+          put(slab_w(3) + kN[3] * kK[3] + 4 * q + r, v3);
+          put(kSlabHead + kP + 4 * q + r, vy);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float vx = row_sum16(hx[i][r]);
+          if (lo == 0) put(kSlabHead + 16 * q + 4 * i + r, vx);
+        }
+      }
+      const float vc = row_sum16(hc);
+      if (lane == 0) put(kSlabHead + kHeadW, vc);
+    }
+    __syncthreads();
+  }
+  float* out = ws + (int64_t)blockIdx.x * kSlab;
+  for (int i = threadIdx.x; i < kSlab; i += kThreads) out[i] = (lds[i] + lds[kSlab + i]) + lds[2 * kSlab + i];
+}
+
 }  // namespace
+
+int ctr_ncf16_slab_floats() { return kSlab; }
+
+int ctr_ncf16_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, const ctr_mlp_head_grad_t* hg,
+                  float* gx, int64_t ldgx, float* workspace, int64_t workspace_floats, int* grid_out, hipStream_t st) {
+  Tower T;
+  for (int l = 0; l < kL; ++l) {
+    if (layers[l].n != kN[l] || layers[l].k != kK[l] || layers[l].act != CTR_ACT_RELU) return CTR_ELIMIT;
+    if (!ctr_aligned16(layers[l].y) || layers[l].ldy % 4 != 0 || !ctr_aligned16(layers[l].w)) return CTR_ELIMIT;
+    T.w[l] = layers[l].w; T.b[l] = layers[l].b; T.y[l] = layers[l].y; T.ldy[l] = layers[l].ldy;
+  }
+  if (hg->p != kP || !gx || !ctr_aligned16(gx) || ldgx % 4 != 0 || !ctr_aligned16(hg->x) || hg->ldx % 4 != 0 ||
+      !ctr_aligned16(hg->gx) || hg->ldgx % 4 != 0)
+    return CTR_ELIMIT;
+  const int64_t groups = ctr_ceil_div(m, 16);
+  int64_t grid = ctr_ceil_div(groups, kWaves);
+  if (grid > 256) grid = 256;   // 172 accumulator registers per lane: one wave per SIMD, one workgroup per CU
+  if (workspace_floats < grid * kSlab) return CTR_ELIMIT;
+  const size_t lds_bytes = sizeof(float) * kBwdLds;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(ncf16_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds_bytes) != hipSuccess)
+    return CTR_ELAUNCH;
+  const HeadBwd H{hg->gprob, hg->ldgprob, hg->prob, hg->ldprob, hg->x, hg->ldx, hg->w, hg->gx, hg->ldgx, hg->act};
+  hipLaunchKernelGGL(ncf16_bwd_kernel, dim3((unsigned)grid), dim3(kThreads), lds_bytes, st, T, x, ldx, m, H, gx, ldgx,
+                     workspace);
+  *grid_out = (int)grid;
+  return ctr_launch_status();
+}
 
 // internal entry (mlp_fused.hip dispatches here for the pinned tower + 64-column head); every pointer checked there
 int ctr_ncf16_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, const ctr_mlp_head_t* head,
