@@ -218,15 +218,27 @@ constexpr int slab_w(int l) {                             // float offset of lay
 }
 constexpr int kSlabHead = slab_w(kL);                     // 11000
 constexpr int kSlab = kSlabHead + kHeadW + 1;             // 11073
-// at the end three waves park their sums side by side (the weights are dead), the fourth adds into the first copy
-constexpr int kBwdLds = 3 * kSlab > kBwdMain ? 3 * kSlab : kBwdMain;
+// at the end three waves park their sums side by side (the weights are dead), the fourth adds into the first copy;
+// a copy = the 43 accumulator vectors in lane order, then the bias sums of the four layers and the head's sums
+constexpr int kVecs = 43;
+constexpr int kVecFloats = kVecs * 256;
+constexpr int small_b(int l) {                            // bias sums of layer l (l = 4: the head's sums) inside "small"
+  int o = 0;
+  for (int i = 0; i < l; ++i) o += kN[i];
+  return o;
+}
+constexpr int kSmall = small_b(kL) + kHeadW + 1;          // 193
+constexpr int kSmallVecs = 13;                            // bias sums 4 + 2 + 1 + 1, head: 1 + 4 (each 4 per lane)
+constexpr int kCopy = kVecFloats + kSmall + 3;            // 11204 (a multiple of 4: every copy stays 16-byte aligned)
+constexpr int kBwdLds = 3 * kCopy > kBwdMain ? 3 * kCopy : kBwdMain;
 
 // transposed A operands: s_wt[wa_off(l) + ((j*B + b)*64 + lane)*4 + c] = W_l[16b + 4(lane/16) + c][16j + lane%16]
-__device__ __forceinline__ void stage_transposed_weights(float* s_wt, const Tower& T) {
+constexpr int kStagePer = (kWFloats / 4 + kThreads - 1) / kThreads;
+// in two halves: the requests go out first, the group operands' requests behind them, and the LDS stores then wait for
+// the weights alone (loads return in order: behind the 72 operand loads they waited for all of those as well)
+__device__ __forceinline__ void stage_transposed_load(const Tower& T, f32x4 (&v)[kStagePer], int (&dst)[kStagePer]) {
   constexpr int kUnits = kWFloats / 4;
-  constexpr int kPer = (kUnits + kThreads - 1) / kThreads;
-  f32x4 v[kPer];
-  int dst[kPer];
+  constexpr int kPer = kStagePer;
 #pragma unroll
   for (int i = 0; i < kPer; ++i) {
     int u = threadIdx.x + i * kThreads;
@@ -245,8 +257,10 @@ __device__ __forceinline__ void stage_transposed_weights(float* s_wt, const Towe
       if (unit < kN[l]) v[i] = ldg4(T.w[l] + (int64_t)unit * kK[l] + 4 * t4);
     }
   }
+}
+__device__ __forceinline__ void stage_transposed_store(float* s_wt, const f32x4 (&v)[kStagePer], const int (&dst)[kStagePer]) {
 #pragma unroll
-  for (int i = 0; i < kPer; ++i)
+  for (int i = 0; i < kStagePer; ++i)
     if (dst[i] >= 0) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) s_wt[dst[i] + 4 * e] = v[i][e];
@@ -336,6 +350,13 @@ __device__ __forceinline__ f32x4 dx_block(const float* s_wt, int lane, int j, co
   return acc;
 }
 
+#ifdef CTR_STAMPS
+__device__ unsigned long long g_stamps[4 * 16];
+#define STAMP(i) do { if (blockIdx.x == 7 && lane == 0) g_stamps[wave * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 __global__ void __launch_bounds__(kThreads)
 ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_t m, const HeadBwd H,
                  float* __restrict__ gx, int64_t ldgx, float* __restrict__ ws) {
@@ -409,8 +430,15 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
 #pragma unroll
       for (int c = 0; c < 4; ++c) x0t[b][c] = x[rt[c] * ldx + 16 * b + lo];
   };
-  fetch_head(wave0); fetch_l3(wave0); fetch_l2(wave0); fetch_l1(wave0); fetch_l0(wave0);
-  stage_transposed_weights(s_wt, T);
+  STAMP(0);
+  {
+    f32x4 wv[kStagePer];
+    int wdst[kStagePer];
+    stage_transposed_load(T, wv, wdst);
+    fetch_head(wave0); fetch_l3(wave0); fetch_l2(wave0); fetch_l1(wave0); fetch_l0(wave0);
+    stage_transposed_store(s_wt, wv, wdst);
+  }
+  STAMP(1);
   for (int i = threadIdx.x; i < kHeadW; i += blockDim.x) s_hw[i] = H.w[i];
   __syncthreads();
 
@@ -434,8 +462,10 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
     for (int j = 0; j < 4; ++j) dw1[b][j] = zero4;
   }
   sb2 = sb3 = dw3 = zero4;
-
-  for (int64_t g = wave0; g < groups; g += nwaves) {
+  STAMP(2);
+  int it = 0;
+  for (int64_t g = wave0; g < groups; g += nwaves, ++it) {
+    STAMP(3 + it);
     const int64_t row = g * 16 + lo;
     const bool live = row < m;
     // ---- head: gz, the extra columns' gradient, the head's sums, the tower's (masked) gY
@@ -530,72 +560,123 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
     }
   }
 
-  // ---- the workgroup's partial (the weights are dead): waves 0..2 store their sums into three copies of the slab at
-  // once, wave 3 then adds into the first copy, and the copies are summed on the way out.  (Four waves taking turns
-  // on one copy were 4 x 690 dependent LDS read-modify-writes per lane: a third of the kernel.)
+  STAMP(8);
+  // ---- the workgroup's partial (the weights are dead).  A copy holds the 43 accumulator vectors exactly as the lanes
+  // hold them (16 B per lane: full-rate, conflict-free LDS traffic), then the 193 bias / head sums; waves 0..2 write three
+  // copies at once, wave 3 adds into the first, and the copies are summed and put into slab order on the way out.
+  // (Stored in slab order the rows of a quarter-wave were 512 floats apart: four-way bank conflicts on 690 scalar
+  // stores per lane, and wave 3's read-modify-write of them, were 30 % of the kernel.)
   __syncthreads();
-  for (int round = 0; round < 2; ++round) {
-    if ((round == 0) == (wave < 3)) {
-      float* slab = lds + (wave < 3 ? wave : 0) * kSlab;
-      const bool add = wave == 3;
-      auto put = [&](int idx, float v) { slab[idx] = add ? slab[idx] + v : v; };
+  {
+    // sums over the samples (the sixteen lanes of a DPP row), four independent chains at a time
+    auto rsum = [&](const f32x4& v) {
+      f32x4 o;
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+      for (int r = 0; r < 4; ++r) o[r] = row_sum16(v[r]);
+      return o;
+    };
+    f32x4 sm[kSmallVecs];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+    for (int b = 0; b < 4; ++b) sm[b] = rsum(sb0[b]);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) put(slab_w(0) + (16 * b + 4 * q + r) * kK[0] + 16 * j + lo, dw0[b][j][r]);
+    for (int b = 0; b < 2; ++b) sm[4 + b] = rsum(sb1[b]);
+    sm[6] = rsum(sb2);
+    sm[7] = rsum(sb3);
+    sm[8] = rsum(hy);
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+    for (int i = 0; i < 4; ++i) sm[9 + i] = rsum(hx[i]);
+    const float vc = row_sum16(hc);
+    // where lane (q, 0) keeps vector i of the small part (16-byte aligned; -1: not this quarter)
+    auto small_at = [&](int i) {
+      return i < 4 ? small_b(0) + 16 * i + 4 * q : i < 6 ? small_b(1) + 16 * (i - 4) + 4 * q
+           : i == 6 ? small_b(2) + 4 * q : i == 7 ? (q < 2 ? small_b(3) + 4 * q : -1)
+           : i == 8 ? (q < 2 ? small_b(4) + kP + 4 * q : -1) : small_b(4) + 16 * q + 4 * (i - 9);
+    };
+    float* copy = lds + (wave < 3 ? wave : 0) * kCopy;
+    float* small = copy + kVecFloats;
+    auto vec = [&](int v) -> const f32x4& {
+      return v < 32 ? dw0[v >> 3][v & 7] : v < 40 ? dw1[(v - 32) >> 2][(v - 32) & 3] : v < 42 ? dw2[v - 40] : dw3;
+    };
+    if (wave < 3) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int v = 0; v < kVecs; ++v) *reinterpret_cast<f32x4*>(copy + (v * 64 + lane) * 4) = vec(v);
+      if (lo == 0) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) put(slab_w(1) + (16 * b + 4 * q + r) * kK[1] + 16 * j + lo, dw1[b][j][r]);
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) put(slab_w(2) + (4 * q + r) * kK[2] + 16 * j + lo, dw2[j][r]);
-      if (q < 2) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) put(slab_w(3) + (4 * q + r) * kK[3] + lo, dw3[r]);
+        for (int i = 0; i < kSmallVecs; ++i)
+          if (small_at(i) >= 0) *reinterpret_cast<f32x4*>(small + small_at(i)) = sm[i];
       }
-      // sums over the samples: the sixteen lanes of a DPP row
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const float v = row_sum16(sb0[b][r]);
-          if (lo == 0) put(slab_w(0) + kN[0] * kK[0] + 16 * b + 4 * q + r, v);
-        }
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const float v = row_sum16(sb1[b][r]);
-          if (lo == 0) put(slab_w(1) + kN[1] * kK[1] + 16 * b + 4 * q + r, v);
-        }
-        const float v2 = row_sum16(sb2[r]), v3 = row_sum16(sb3[r]), vy = row_sum16(hy[r]);
-        if (lo == 0) put(slab_w(2) + kN[2] * kK[2] + 4 * q + r, v2);
-        if (lo == 0 && q < 2) {
-          put(slab_w(3) + kN[3] * kK[3] + 4 * q + r, v3);
-          put(kSlabHead + kP + 4 * q + r, vy);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float vx = row_sum16(hx[i][r]);
-          if (lo == 0) put(kSlabHead + 16 * q + 4 * i + r, vx);
-        }
-      }
-      const float vc = row_sum16(hc);
-      if (lane == 0) put(kSlabHead + kHeadW, vc);
+      if (lane == 0) small[small_b(4) + kHeadW] = vc;
     }
     __syncthreads();
+    STAMP(9);
+    if (wave == 3) {
+      // read-modify-write of the first copy, the reads a dozen at a time (one at a time each waited out its own
+      // LDS round trip: 12 K cycles for 56 of them)
+      constexpr int kBatch = 11;
+#pragma unroll
+      for (int v0 = 0; v0 < kVecs; v0 += kBatch) {
+        f32x4 old[kBatch];
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i)
+          if (v0 + i < kVecs) old[i] = *reinterpret_cast<const f32x4*>(copy + ((v0 + i) * 64 + lane) * 4);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < kBatch; ++i)
+          if (v0 + i < kVecs) *reinterpret_cast<f32x4*>(copy + ((v0 + i) * 64 + lane) * 4) = old[i] + vec(v0 + i);
+        asm volatile("" ::: "memory");
+      }
+      if (lo == 0) {
+        f32x4 old[kSmallVecs];
+#pragma unroll
+        for (int i = 0; i < kSmallVecs; ++i)
+          if (small_at(i) >= 0) old[i] = *reinterpret_cast<const f32x4*>(small + small_at(i));
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < kSmallVecs; ++i)
+          if (small_at(i) >= 0) *reinterpret_cast<f32x4*>(small + small_at(i)) = old[i] + sm[i];
+      }
+      if (lane == 0) small[small_b(4) + kHeadW] += vc;
+    }
+    __syncthreads();
+    STAMP(10);
   }
   float* out = ws + (int64_t)blockIdx.x * kSlab;
-  for (int i = threadIdx.x; i < kSlab; i += kThreads) out[i] = (lds[i] + lds[kSlab + i]) + lds[2 * kSlab + i];
+#pragma unroll
+  for (int i = 0; i < (kVecs + kWaves - 1) / kWaves; ++i) {
+    const int v = wave + kWaves * i;                          // uniform over the wave
+    if (v < kVecs) {
+      const int at = (v * 64 + lane) * 4;
+      const f32x4 sum = (*reinterpret_cast<const f32x4*>(lds + at) + *reinterpret_cast<const f32x4*>(lds + kCopy + at)) +
+                        *reinterpret_cast<const f32x4*>(lds + 2 * kCopy + at);
+      const int l = v < 32 ? 0 : v < 40 ? 1 : v < 42 ? 2 : 3;
+      const int vv = v - (l == 0 ? 0 : l == 1 ? 32 : l == 2 ? 40 : 42);
+      const int J = l == 0 ? 8 : l == 1 ? 4 : l == 2 ? 2 : 1, K = l == 0 ? kK[0] : l == 1 ? kK[1] : l == 2 ? kK[2] : kK[3];
+      const int bb = vv / J, jj = vv - bb * J;
+      const int base = (l == 0 ? slab_w(0) : l == 1 ? slab_w(1) : l == 2 ? slab_w(2) : slab_w(3)) +
+                       (16 * bb + 4 * q) * K + 16 * jj + lo;
+      if (l < 3 || q < 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[base + r * K] = sum[r];
+      }
+    }
+  }
+  for (int i = threadIdx.x; i < kSmall; i += kThreads) {
+    const int l = i < small_b(1) ? 0 : i < small_b(2) ? 1 : i < small_b(3) ? 2 : i < small_b(4) ? 3 : 4;
+    const int dst = l == 4 ? kSlabHead + (i - small_b(4)) : slab_w(l) + kN[l] * kK[l] + (i - small_b(l));
+    const int at = kVecFloats + i;
+    out[dst] = (lds[at] + lds[kCopy + at]) + lds[2 * kCopy + at];
+  }
+  STAMP(11);
 }
 
 }  // namespace
 
 int ctr_ncf16_slab_floats() { return kSlab; }
+#ifdef CTR_STAMPS
+extern "C" __attribute__((visibility("default"))) int ctr_ncf16_debug_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 64);
+}
+#endif
 
 int ctr_ncf16_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, const ctr_mlp_head_grad_t* hg,
                   float* gx, int64_t ldgx, float* workspace, int64_t workspace_floats, int* grid_out, hipStream_t st) {
