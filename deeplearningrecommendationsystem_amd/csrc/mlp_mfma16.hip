@@ -209,7 +209,8 @@ struct HeadBwd {
 };
 
 constexpr int kTS = 20;                                   // row stride of a transposition tile (16-byte aligned rows)
-constexpr int kStrip = 4 * 16 * kTS;                      // four tiles per wave
+constexpr int kTile = 16 * kTS;
+constexpr int kStrip = 6 * kTile;                         // per wave: tiles A0 A1 | B0..B3 (layers alternate)
 constexpr int kBwdMain = kWFloats + kWaves * kStrip;      // floats: transposed weights, then the waves' strips
 constexpr int slab_w(int l) {                             // float offset of layer l's dW inside a slab
   int o = 0;
@@ -233,30 +234,37 @@ constexpr int kCopy = kVecFloats + kSmall + 3;            // 11204 (a multiple o
 constexpr int kBwdLds = 3 * kCopy > kBwdMain ? 3 * kCopy : kBwdMain;
 
 // transposed A operands: s_wt[wa_off(l) + ((j*B + b)*64 + lane)*4 + c] = W_l[16b + 4(lane/16) + c][16j + lane%16]
-constexpr int kStagePer = (kWFloats / 4 + kThreads - 1) / kThreads;
+// dwordx4 units a thread stages per layer (2048, 512, 128, 64 units over 256 threads), and where they start in its arrays
+constexpr int stage_per(int l) { return (16 * blocks(kN[l]) * (kK[l] / 4) + kThreads - 1) / kThreads; }
+constexpr int stage_off(int l) {
+  int o = 0;
+  for (int i = 0; i < l; ++i) o += stage_per(i);
+  return o;
+}
+constexpr int kStagePer = stage_off(kL);                  // 12
+template <int L>
+__device__ __forceinline__ void stage_layer_load(const Tower& T, f32x4 (&v)[kStagePer], int (&dst)[kStagePer]) {
+  constexpr int K4 = kK[L] / 4, B = blocks(kN[L]), U = 16 * B * K4;
+#pragma unroll
+  for (int i = 0; i < stage_per(L); ++i) {
+    const int u = threadIdx.x + i * kThreads, at = stage_off(L) + i;
+    v[at] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dst[at] = -1;
+    if (u < U) {
+      const int unit = u / K4, t4 = u % K4;               // W_L[unit][4 t4 .. 4 t4 + 3]  (K4 is a power of two)
+      const int b = unit >> 4, qq = (unit >> 2) & 3, c = unit & 3, j = t4 >> 2, lo0 = (4 * t4) & 15;
+      dst[at] = wa_off(L) + ((j * B + b) * 64 + qq * 16 + lo0) * 4 + c;   // + 4 per consecutive input
+      if (unit < kN[L]) v[at] = ldg4(T.w[L] + unit * kK[L] + 4 * t4);
+    }
+  }
+}
 // in two halves: the requests go out first, the group operands' requests behind them, and the LDS stores then wait for
 // the weights alone (loads return in order: behind the 72 operand loads they waited for all of those as well)
 __device__ __forceinline__ void stage_transposed_load(const Tower& T, f32x4 (&v)[kStagePer], int (&dst)[kStagePer]) {
-  constexpr int kUnits = kWFloats / 4;
-  constexpr int kPer = kStagePer;
-#pragma unroll
-  for (int i = 0; i < kPer; ++i) {
-    int u = threadIdx.x + i * kThreads;
-    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    dst[i] = -1;
-    if (u < kUnits) {
-      int l = 0;
-#pragma unroll
-      for (int t = 0; t < kL - 1; ++t)
-        if (u >= wa_off(t + 1) / 4) l = t + 1;
-      u -= wa_off(l) / 4;
-      const int K4 = kK[l] / 4, B = blocks(kN[l]);
-      const int unit = u / K4, t4 = u - unit * K4;        // W_l[unit][4 t4 .. 4 t4 + 3]
-      const int b = unit >> 4, qq = (unit >> 2) & 3, c = unit & 3, j = t4 >> 2, lo0 = (4 * t4) & 15;
-      dst[i] = wa_off(l) + ((j * B + b) * 64 + qq * 16 + lo0) * 4 + c;   // + 4 per consecutive input
-      if (unit < kN[l]) v[i] = ldg4(T.w[l] + (int64_t)unit * kK[l] + 4 * t4);
-    }
-  }
+  stage_layer_load<0>(T, v, dst);
+  stage_layer_load<1>(T, v, dst);
+  stage_layer_load<2>(T, v, dst);
+  stage_layer_load<3>(T, v, dst);
 }
 __device__ __forceinline__ void stage_transposed_store(float* s_wt, const f32x4 (&v)[kStagePer], const int (&dst)[kStagePer]) {
 #pragma unroll
@@ -283,71 +291,72 @@ __device__ __forceinline__ f32x4 relu_mask(const f32x4& g, const f32x4& y) {
   return o;
 }
 
-// sample-major block (lane (q, n): units 4q + r of sample n) -> unit-major (lane (q, u): unit u, samples 4q + c)
-__device__ __forceinline__ f32x4 transpose_block(float* tile, int q, int lo, const f32x4& v) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) tile[(4 * q + r) * kTS + lo] = v[r];
-  __builtin_amdgcn_wave_barrier();
-  const f32x4 t = *reinterpret_cast<const f32x4*>(tile + lo * kTS + 4 * q);
-  __builtin_amdgcn_wave_barrier();
-  return t;
-}
-
-template <int NB>   // NB blocks at once: all writes, one barrier, all reads
-__device__ __forceinline__ void transpose_blocks(float* strip, int q, int lo, const f32x4 (&v)[NB], f32x4 (&t)[NB]) {
+// Transposition of gradient blocks through the wave's LDS tiles, in two halves so that matrix-core work sits between
+// the stores and the loads.  sample-major block (lane (q, n): units 4q + r of sample n) -> unit-major (lane (q, u):
+// unit u, samples 4q + c).  The LDS pipe serves a wave's requests in order; the clobbers keep the compiler from
+// reordering them.
+template <int NB>
+__device__ __forceinline__ void tiles_put(float* tiles, int q, int lo, const f32x4 (&v)[NB]) {
+  asm volatile("" ::: "memory");
 #pragma unroll
   for (int b = 0; b < NB; ++b)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) strip[b * 16 * kTS + (4 * q + r) * kTS + lo] = v[b][r];
-  __builtin_amdgcn_wave_barrier();
+    for (int r = 0; r < 4; ++r) tiles[b * kTile + (4 * q + r) * kTS + lo] = v[b][r];
+  asm volatile("" ::: "memory");
+}
+template <int NB>
+__device__ __forceinline__ void tiles_get(const float* tiles, int q, int lo, f32x4 (&t)[NB]) {
+  asm volatile("" ::: "memory");
 #pragma unroll
-  for (int b = 0; b < NB; ++b) t[b] = *reinterpret_cast<const f32x4*>(strip + b * 16 * kTS + lo * kTS + 4 * q);
-  __builtin_amdgcn_wave_barrier();
+  for (int b = 0; b < NB; ++b) t[b] = *reinterpret_cast<const f32x4*>(tiles + b * kTile + lo * kTS + 4 * q);
+  asm volatile("" ::: "memory");
 }
 
-// two dX^T blocks of layer L at once (independent accumulator chains)
-template <int L, int NB>
-__device__ __forceinline__ void dx_block2(const float* s_wt, int lane, int j, const f32x4 (&gz)[NB], f32x4& o0, f32x4& o1) {
-  constexpr int B = blocks(kN[L]);
-  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-  const float* wb0 = s_wt + wa_off(L) + ((j * B) * 64 + lane) * 4;
-  const float* wb1 = wb0 + B * 256;
-  f32x4 w0 = *reinterpret_cast<const f32x4*>(wb0), w1 = *reinterpret_cast<const f32x4*>(wb1);
-#pragma unroll
-  for (int b = 0; b < B; ++b) {
-    const f32x4 wa = w0, wc = w1;
-    if (b + 1 < B) {
-      w0 = *reinterpret_cast<const f32x4*>(wb0 + (b + 1) * 256);
-      w1 = *reinterpret_cast<const f32x4*>(wb1 + (b + 1) * 256);
-    }
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c], gz[b][c], a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[c], gz[b][c], a1, 0, 0, 0);
-    }
-  }
-  o0 = a0;
-  o1 = a1;
+// dX^T of layer L: out block j = sum_b sum_c WT_L[j][b][lane][c] (x) gz[b][c]   (out in the layout of gz).
+// The weight vectors are read one step ahead over the whole layer; the first pair comes in (requested by dx_first
+// before the preceding dW products), so no LDS round trip is waited out in front of the chain.
+template <int L>
+__device__ __forceinline__ void dx_first(const float* s_wt, int lane, f32x4& w0, f32x4& w1) {
+  constexpr int B = blocks(kN[L]), JO = blocks(kK[L]);
+  const float* base = s_wt + wa_off(L) + lane * 4;
+  asm volatile("" ::: "memory");
+  w0 = *reinterpret_cast<const f32x4*>(base);
+  if (JO > 1) w1 = *reinterpret_cast<const f32x4*>(base + B * 256);
+  asm volatile("" ::: "memory");
 }
-
-// dX^T block(s) of layer L: out[j] = sum_b sum_c WT_L[j][b][lane][c] (x) gz[b][c]   (out in the layout of gz)
-template <int L, int NB>
-__device__ __forceinline__ f32x4 dx_block(const float* s_wt, int lane, int j, const f32x4 (&gz)[NB]) {
-  constexpr int B = blocks(kN[L]);
+template <int L, int NB, typename Sink>
+__device__ __forceinline__ void dx_layer(const float* s_wt, int lane, const f32x4 (&gz)[NB], f32x4 w0, f32x4 w1, Sink&& sink) {
+  constexpr int B = blocks(kN[L]), JO = blocks(kK[L]);
   static_assert(B == NB, "gradient blocks");
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const float* wbase = s_wt + wa_off(L) + ((j * B) * 64 + lane) * 4;
-  f32x4 w0 = *reinterpret_cast<const f32x4*>(wbase);
+  const float* base = s_wt + wa_off(L) + lane * 4;
+  if constexpr (JO == 1) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    static_assert(B == 1, "single output block: single contraction block");
 #pragma unroll
-  for (int b = 0; b < B; ++b) {
-    const f32x4 wa = w0;
-    if (b + 1 < B) w0 = *reinterpret_cast<const f32x4*>(wbase + (b + 1) * 256);
-    asm volatile("" ::: "memory");
+    for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[c], gz[0][c], acc, 0, 0, 0);
+    sink(0, acc, acc);
+  } else {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c], gz[b][c], acc, 0, 0, 0);
+    for (int j = 0; j < JO; j += 2) {
+      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+      for (int b = 0; b < B; ++b) {
+        const f32x4 wa = w0, wc = w1;
+        const int nj = b + 1 < B ? j : j + 2, nb = b + 1 < B ? b + 1 : 0;
+        if (nj < JO) {
+          w0 = *reinterpret_cast<const f32x4*>(base + (nj * B + nb) * 256);
+          w1 = *reinterpret_cast<const f32x4*>(base + ((nj + 1) * B + nb) * 256);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c], gz[b][c], a0, 0, 0, 0);
+          a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[c], gz[b][c], a1, 0, 0, 0);
+        }
+      }
+      sink(j, a0, a1);
+    }
   }
-  return acc;
 }
 
 #ifdef CTR_STAMPS
@@ -364,7 +373,8 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
   __shared__ __attribute__((aligned(16))) float s_hw[kHeadW];
   float* s_wt = lds;
   const int lane = threadIdx.x & 63, q = lane >> 4, lo = lane & 15, wave = threadIdx.x >> 6;
-  float* strip = lds + kWFloats + wave * kStrip;
+  float* tA = lds + kWFloats + wave * kStrip;   // tiles of layers 3 and 1
+  float* tB = tA + 2 * kTile;                    // tiles of layers 2 and 0
   const int64_t groups = (m + 15) / 16;
   const int64_t wave0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * kThreads) >> 6;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -463,9 +473,16 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
   }
   sb2 = sb3 = dw3 = zero4;
   STAMP(2);
+  // ---- the walk.  Per layer: dX products first (their weights stream from LDS, the first pair requested ahead), the
+  // next layer's gradient goes to the other tile set, then the dW products cover that LDS round trip.  The operands of
+  // the next group are requested as registers free.  Consecutive matrix-core instructions never share an accumulator
+  // where the shape allows (a dependent v_mfma_f32_16x16x4_f32 issues after 40 cycles, an independent one after 32).
+  // (Threading the next group's head and layers 3 / 2 through the dW_0 products was measured too: the vector and LDS
+  // instructions cost the same cycles between matrix-core instructions as in front of them, and the extra live state
+  // spilled: DESIGN.md section 9.)
   int it = 0;
   for (int64_t g = wave0; g < groups; g += nwaves, ++it) {
-    STAMP(3 + it);
+    if (it < 4) STAMP(3 + it);
     const int64_t row = g * 16 + lo;
     const bool live = row < m;
     // ---- head: gz, the extra columns' gradient, the head's sums, the tower's (masked) gY
@@ -483,81 +500,84 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
       hy += gz * y4d;                                         // (y4d is zero for q >= 2)
       gz3[0] = relu_mask(gz * wv, y4d);
     }
+    sb3 += gz3[0];
+    tiles_put<1>(tA, q, lo, gz3);
+    f32x4 w0 = zero4, w1 = zero4;
+    dx_first<3>(s_wt, lane, w0, w1);
     fetch_head(g + nwaves);
     // ---- layer 3 (16 -> 8)
-    sb3 += gz3[0];
-    {
-      const f32x4 tg = transpose_block(strip, q, lo, gz3[0]);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) dw3 = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[c], y3t[c], dw3, 0, 0, 0);
-    }
     f32x4 gz2[1];
-    gz2[0] = relu_mask(dx_block<3, 1>(s_wt, lane, 0, gz3), y3d);
+    {
+      f32x4 tg[1];
+      tiles_get<1>(tA, q, lo, tg);
+      dx_layer<3, 1>(s_wt, lane, gz3, w0, w1, [&](int, const f32x4& d0, const f32x4&) { gz2[0] = relu_mask(d0, y3d); });
+      sb2 += gz2[0];
+      tiles_put<1>(tB, q, lo, gz2);
+      dx_first<2>(s_wt, lane, w0, w1);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) dw3 = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[0][c], y3t[c], dw3, 0, 0, 0);
+    }
     fetch_l3(g + nwaves);
     // ---- layer 2 (32 -> 16)
-    sb2 += gz2[0];
-    {
-      const f32x4 tg = transpose_block(strip, q, lo, gz2[0]);
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) dw2[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[c], y2t[j][c], dw2[j], 0, 0, 0);
-    }
     f32x4 gz1[2];
     {
-      f32x4 d0, d1;
-      dx_block2<2, 1>(s_wt, lane, 0, gz2, d0, d1);
-      gz1[0] = relu_mask(d0, y2d[0]);
-      gz1[1] = relu_mask(d1, y2d[1]);
+      f32x4 tg[1];
+      tiles_get<1>(tB, q, lo, tg);
+      dx_layer<2, 1>(s_wt, lane, gz2, w0, w1, [&](int, const f32x4& d0, const f32x4& d1) {
+        gz1[0] = relu_mask(d0, y2d[0]);
+        gz1[1] = relu_mask(d1, y2d[1]);
+      });
+#pragma unroll
+      for (int b = 0; b < 2; ++b) sb1[b] += gz1[b];
+      tiles_put<2>(tA, q, lo, gz1);
+      dx_first<1>(s_wt, lane, w0, w1);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dw2[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[0][c], y2t[j][c], dw2[j], 0, 0, 0);
     }
     fetch_l2(g + nwaves);
     // ---- layer 1 (64 -> 32)
+    f32x4 gz0[4];
     {
       f32x4 tg[2];
-#pragma unroll
-      for (int b = 0; b < 2; ++b) sb1[b] += gz1[b];
-      transpose_blocks<2>(strip, q, lo, gz1, tg);
+      tiles_get<2>(tA, q, lo, tg);
+      dx_layer<1, 2>(s_wt, lane, gz1, w0, w1, [&](int j, const f32x4& d0, const f32x4& d1) {
+        gz0[j] = relu_mask(d0, y1d[j]);
+        gz0[j + 1] = relu_mask(d1, y1d[j + 1]);
+        sb0[j] += gz0[j];
+        sb0[j + 1] += gz0[j + 1];
+      });
+      tiles_put<4>(tB, q, lo, gz0);
+      dx_first<0>(s_wt, lane, w0, w1);
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
+          for (int j = 0; j < 4; ++j)
             dw1[b][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[b][c], y1t[j][c], dw1[b][j], 0, 0, 0);
-    }
-    f32x4 gz0[4];
-#pragma unroll
-    for (int j = 0; j < 4; j += 2) {
-      f32x4 d0, d1;
-      dx_block2<1, 2>(s_wt, lane, j, gz1, d0, d1);
-      gz0[j] = relu_mask(d0, y1d[j]);
-      gz0[j + 1] = relu_mask(d1, y1d[j + 1]);
     }
     fetch_l1(g + nwaves);
     // ---- layer 0 (128 -> 64)
     {
       f32x4 tg[4];
+      tiles_get<4>(tB, q, lo, tg);
+      dx_layer<0, 4>(s_wt, lane, gz0, w0, w1, [&](int j, const f32x4& d0, const f32x4& d1) {
+        if (live) {
+          stg4(gx + row * ldgx + 16 * j + 4 * q, d0);
+          stg4(gx + row * ldgx + 16 * (j + 1) + 4 * q, d1);
+        }
+      });
 #pragma unroll
-      for (int b = 0; b < 4; ++b) sb0[b] += gz0[b];
-      transpose_blocks<4>(strip, q, lo, gz0, tg);
+      for (int b = 0; b < 4; ++b)
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
+          for (int j = 0; j < 8; ++j)
             dw0[b][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[b][c], x0t[j][c], dw0[b][j], 0, 0, 0);
     }
-    fetch_l0(g + nwaves);   // x of the next group lands under dX_0 and the next group's upper layers
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-      f32x4 d0, d1;
-      dx_block2<0, 4>(s_wt, lane, j, gz0, d0, d1);
-      if (live) {
-        stg4(gx + row * ldgx + 16 * j + 4 * q, d0);
-        stg4(gx + row * ldgx + 16 * (j + 1) + 4 * q, d1);
-      }
-    }
+    fetch_l0(g + nwaves);   // x of the next group: needed last, a whole group from now
   }
 
   STAMP(8);
