@@ -386,61 +386,70 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
   // Requested per layer, for the NEXT group, as soon as this group has consumed the registers: every load then has
   // most of a group's time (~10 us) to land.  (All 72 requested together in front of dX_0 left 37 % of the wave's life
   // in s_waitcnt: every wave of the chip issued its burst at the same moment.)
-  auto rows_of = [&](int64_t g, int64_t& rc, bool& live, int64_t (&rt)[4]) {
+  // Row offsets are 32-bit (the entry point checks m * ld < 2^30 for every operand): one multiply per address in
+  // place of a 64-bit product, and the loads take the "scalar base + 32-bit lane offset" form.
+  auto rows_of = [&](int64_t g, uint32_t& rc, bool& live, uint32_t (&rt)[4]) {
+#ifdef CTR_STAMPS_HOT
+    g &= 63;   // timing experiment: every wave reads cache-resident rows (results are wrong)
+#endif
     const int64_t row = g * 16 + lo;
     live = g < groups && row < m;
-    rc = live ? row : (m - 1);
+    rc = (uint32_t)(live ? row : (m - 1));
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      rt[c] = g * 16 + 4 * q + c;
-      if (g >= groups || rt[c] >= m) rt[c] = m - 1;          // meets a zero gradient
+      const int64_t r = g * 16 + 4 * q + c;
+      rt[c] = (uint32_t)((g >= groups || r >= m) ? (m - 1) : r);   // (a clamped row meets a zero gradient)
     }
   };
+  auto at = [](const float* base, uint32_t row, uint32_t ld, uint32_t col) {
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (row * ld + col) * 4u);
+  };
+  const uint32_t ld0 = (uint32_t)T.ldy[0], ld1 = (uint32_t)T.ldy[1], ld2 = (uint32_t)T.ldy[2], ld3 = (uint32_t)T.ldy[3];
+  const uint32_t ldx32 = (uint32_t)ldx, ldxe = (uint32_t)H.ldxe;
   auto fetch_head = [&](int64_t g) {
-    int64_t rc, rt[4]; bool live;
+    uint32_t rc, rt[4]; bool live;
     rows_of(g, rc, live, rt);
-    gp = live ? H.gprob[rc * H.ldgp] : 0.0f;                 // a dead lane's gz is zero: it adds nothing anywhere
-    pb = H.prob[rc * H.ldp];
-    y4d = q < 2 ? ldg4(T.y[3] + rc * T.ldy[3] + 4 * q) : zero4;
+    gp = live ? *at(H.gprob, rc, (uint32_t)H.ldgp, 0) : 0.0f;   // a dead lane's gz is zero: it adds nothing anywhere
+    pb = *at(H.prob, rc, (uint32_t)H.ldp, 0);
+    y4d = q < 2 ? ldg4(at(T.y[3], rc, ld3, 4 * q)) : zero4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xe[i] = ldg4(H.xe + rc * H.ldxe + 16 * q + 4 * i);
+    for (int i = 0; i < 4; ++i) xe[i] = ldg4(at(H.xe, rc, ldxe, 16 * q + 4 * i));
   };
   auto fetch_l3 = [&](int64_t g) {
-    int64_t rc, rt[4]; bool live;
+    uint32_t rc, rt[4]; bool live;
     rows_of(g, rc, live, rt);
-    y3d = ldg4(T.y[2] + rc * T.ldy[2] + 4 * q);
+    y3d = ldg4(at(T.y[2], rc, ld2, 4 * q));
 #pragma unroll
-    for (int c = 0; c < 4; ++c) y3t[c] = T.y[2][rt[c] * T.ldy[2] + lo];
+    for (int c = 0; c < 4; ++c) y3t[c] = *at(T.y[2], rt[c], ld2, lo);
   };
   auto fetch_l2 = [&](int64_t g) {
-    int64_t rc, rt[4]; bool live;
+    uint32_t rc, rt[4]; bool live;
     rows_of(g, rc, live, rt);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      y2d[b] = ldg4(T.y[1] + rc * T.ldy[1] + 16 * b + 4 * q);
+      y2d[b] = ldg4(at(T.y[1], rc, ld1, 16 * b + 4 * q));
 #pragma unroll
-      for (int c = 0; c < 4; ++c) y2t[b][c] = T.y[1][rt[c] * T.ldy[1] + 16 * b + lo];
+      for (int c = 0; c < 4; ++c) y2t[b][c] = *at(T.y[1], rt[c], ld1, 16 * b + lo);
     }
   };
   auto fetch_l1 = [&](int64_t g) {
-    int64_t rc, rt[4]; bool live;
+    uint32_t rc, rt[4]; bool live;
     rows_of(g, rc, live, rt);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      y1d[b] = ldg4(T.y[0] + rc * T.ldy[0] + 16 * b + 4 * q);
+      y1d[b] = ldg4(at(T.y[0], rc, ld0, 16 * b + 4 * q));
 #pragma unroll
-      for (int c = 0; c < 4; ++c) y1t[b][c] = T.y[0][rt[c] * T.ldy[0] + 16 * b + lo];
+      for (int c = 0; c < 4; ++c) y1t[b][c] = *at(T.y[0], rt[c], ld0, 16 * b + lo);
     }
   };
   auto fetch_l0 = [&](int64_t g) {
-    int64_t rc, rt[4]; bool live;
+    uint32_t rc, rt[4]; bool live;
     rows_of(g, rc, live, rt);
 #pragma unroll
     for (int b = 0; b < 8; ++b)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) x0t[b][c] = x[rt[c] * ldx + 16 * b + lo];
+      for (int c = 0; c < 4; ++c) x0t[b][c] = *at(x, rt[c], ldx32, 16 * b + lo);
   };
-  STAMP(0);
   {
     f32x4 wv[kStagePer];
     int wdst[kStagePer];
@@ -709,6 +718,12 @@ int ctr_ncf16_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t*
   if (hg->p != kP || !gx || !ctr_aligned16(gx) || ldgx % 4 != 0 || !ctr_aligned16(hg->x) || hg->ldx % 4 != 0 ||
       !ctr_aligned16(hg->gx) || hg->ldgx % 4 != 0)
     return CTR_ELIMIT;
+  // 32-bit byte offsets inside every operand the kernel reads
+  int64_t widest = ldx > hg->ldx ? ldx : hg->ldx;
+  for (int l = 0; l < kL; ++l) widest = layers[l].ldy > widest ? layers[l].ldy : widest;
+  widest = hg->ldgprob > widest ? hg->ldgprob : widest;
+  widest = hg->ldprob > widest ? hg->ldprob : widest;
+  if (m * widest >= ((int64_t)1 << 30)) return CTR_ELIMIT;
   const int64_t groups = ctr_ceil_div(m, 16);
   int64_t grid = ctr_ceil_div(groups, kWaves);
   if (grid > 256) grid = 256;   // 172 accumulator registers per lane: one wave per SIMD, one workgroup per CU
