@@ -313,8 +313,8 @@ def gather_stage_leg(device, reps: int = 30):
 
 # kernel label (ops.py) -> kernel name in the rocprofv3 / PMC summaries under profiles/
 # label of an event-bracketed call -> the kernel name prefixes it may appear under in the PMC table (first match wins)
-KERNEL_NAMES = {"embed_fwd_fast": ("embed_ids_fast_kernel",), "mlp_fused_bwd": ("mlp_bwd_kernel",),
-                "mlp_fused_fwd": ("mlp_fwd_direct_kernel", "mlp_fwd_kernel"),
+KERNEL_NAMES = {"embed_fwd_fast": ("embed_ids_fast_kernel",), "mlp_fused_bwd": ("ncf16_bwd_kernel", "mlp_bwd_kernel"),
+                "mlp_fused_fwd": ("ncf16_fwd_kernel", "mlp_fwd_direct_kernel", "mlp_fwd_kernel"),
                 "embed_fwd": ("embed_rows_fast_kernel", "embed_fwd_kernel"),
                 "embed_bwd": ("seg_reduce_kernel", "embed_bwd_kernel"), "mf_fwd": ("mf_fwd_kernel",),
                 "mf_bwd": ("mf_bwd_kernel",)}
@@ -322,7 +322,7 @@ KERNEL_NAMES = {"embed_fwd_fast": ("embed_ids_fast_kernel",), "mlp_fused_bwd": (
 
 # what one event-bracketed C-ABI call covers when it is more than one kernel
 LABEL_NOTES = {
-    "mlp_fused_bwd": "one ctr_mlp_bwd call = mlp_bwd_kernel + reduce_segments_kernel (+ the gap between them); "
+    "mlp_fused_bwd": "one ctr_mlp_head_bwd call = ncf16_bwd_kernel (mlp_bwd_kernel for other stacks) + reduce_segments_kernel (+ the gap between them); "
                      "rocprofv3 lists them separately in profiles/*_kernel_stats.csv",
     "embed_bwd": "one ctr_embed_bwd call = sort_count/colscan/scatter + seg_reduce (small tables) and/or "
                  "bag_bwd + reduce_segments and/or embed_bwd_kernel",
