@@ -450,16 +450,23 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
 #pragma unroll
       for (int c = 0; c < 4; ++c) x0t[b][c] = *at(x, rt[c], ldx32, 16 * b + lo);
   };
+  STAMP(0);
   {
     f32x4 wv[kStagePer];
     int wdst[kStagePer];
     stage_transposed_load(T, wv, wdst);
-    fetch_head(wave0); fetch_l3(wave0); fetch_l2(wave0); fetch_l1(wave0); fetch_l0(wave0);
+    STAMP(12);
+    // (a wave has at most 63 vector-memory operations in flight: with all 84 requested here the issue itself stalled
+    // on the first cold loads for 6 K cycles.  x of the first group is needed last: requested behind the stores.)
+    fetch_head(wave0); fetch_l3(wave0); fetch_l2(wave0); fetch_l1(wave0);
+    STAMP(13);
     stage_transposed_store(s_wt, wv, wdst);
+    fetch_l0(wave0);
   }
-  STAMP(1);
+  STAMP(14);
   for (int i = threadIdx.x; i < kHeadW; i += blockDim.x) s_hw[i] = H.w[i];
   __syncthreads();
+  STAMP(1);
 
   // ---- what a lane sums over every group it walks
   f32x4 dw0[4][8], dw1[2][4], dw2[2], dw3;                   // dW blocks: register r = row 4q + r, column lo

@@ -17,7 +17,7 @@ buf = (ctypes.c_ulonglong * 64)()
 lib = _lib.load()
 lib.ctr_ncf16_debug_stamps.argtypes = [ctypes.c_void_p]
 rc = lib.ctr_ncf16_debug_stamps(buf)
-names = {0: "start", 1: "staged", 2: "zeroed", 3: "g0", 4: "g1", 5: "g2", 6: "g3", 8: "loop end", 9: "round0", 10: "round1", 11: "out"}
+names = {0: "start", 12: "w requested", 13: "operands requested", 14: "w in LDS", 1: "staged", 2: "zeroed", 3: "g0", 4: "g1", 5: "g2", 6: "g3", 8: "loop end", 9: "round0", 10: "round1", 11: "out"}
 for w in range(4):
     st = [buf[w * 16 + i] for i in range(16)]
     print(f"wave {w}: " + "  ".join(f"{n}={st[i] - st[0]}" for i, n in names.items() if i == 0 or st[i]))
