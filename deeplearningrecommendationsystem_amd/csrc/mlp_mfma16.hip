@@ -70,36 +70,50 @@ __device__ __forceinline__ void stg4(float* p, const f32x4& v) { *reinterpret_ca
 // (rows past n: zero -- their outputs stay relu(0) = 0 and are never stored).  A dwordx4 of a weight row (inputs
 // 4t .. 4t+3) is one dwordx4 of the operand order (same block j, same lane, chunks 0..3): coalesced loads, all of a
 // thread's ~11 in flight before the first LDS store (one element at a time this was 43 dependent round trips).
-__device__ __forceinline__ void stage_forward_weights(float* s_w, float* s_b, const Tower& T) {
-  constexpr int kUnits = kWFloats / 4;                       // dwordx4 units over all layers
-  constexpr int kPer = (kUnits + kThreads - 1) / kThreads;   // 11
-  f32x4 v[kPer];
-  int dst[kPer];
+// Index math per layer with compile-time shapes, one `if` per bias / head-weight element: the prologue is executed by
+// every wave, and with three workgroups per CU its ~1600 instructions per wave were a third of a SIMD's issue time
+// (SQ counters: 1254 vector instructions per wave of which 229 matrix products).
+constexpr int fstage_per(int l) { return (16 * blocks(kN[l]) * (kK[l] / 4) + kThreads - 1) / kThreads; }
+constexpr int fstage_off(int l) {
+  int o = 0;
+  for (int i = 0; i < l; ++i) o += fstage_per(i);
+  return o;
+}
+constexpr int kFStagePer = fstage_off(kL);                   // 12
+template <int L>
+__device__ __forceinline__ void stage_forward_layer(const Tower& T, f32x4 (&v)[kFStagePer], int (&dst)[kFStagePer]) {
+  constexpr int K4 = kK[L] / 4, J = blocks(kK[L]), U = 16 * blocks(kN[L]) * K4;
 #pragma unroll
-  for (int i = 0; i < kPer; ++i) {
-    int u = threadIdx.x + i * kThreads;
-    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    dst[i] = -1;
-    if (u < kUnits) {
-      int l = 0;
-#pragma unroll
-      for (int t = 0; t < kL - 1; ++t)
-        if (u >= wa_off(t + 1) / 4) l = t + 1;
-      u -= wa_off(l) / 4;
-      const int K4 = kK[l] / 4, J = blocks(kK[l]);
-      const int unit = u / K4, t4 = u - unit * K4;            // row `unit` (padded to whole blocks), inputs 4 t4 ..
+  for (int i = 0; i < fstage_per(L); ++i) {
+    const int u = threadIdx.x + i * kThreads, at = fstage_off(L) + i;
+    v[at] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dst[at] = -1;
+    if (u < U) {
+      const int unit = u / K4, t4 = u % K4;                  // row `unit` (padded to whole blocks), inputs 4 t4 ..
       const int b = unit >> 4, j = t4 >> 2, qq = t4 & 3;
-      dst[i] = wa_off(l) + ((b * J + j) * 64 + qq * 16 + (unit & 15)) * 4;
-      if (unit < kN[l]) v[i] = ldg4(T.w[l] + (int64_t)unit * kK[l] + 4 * t4);
+      dst[at] = wa_off(L) + ((b * J + j) * 64 + qq * 16 + (unit & 15)) * 4;
+      if (unit < kN[L]) v[at] = ldg4(T.w[L] + unit * kK[L] + 4 * t4);
     }
   }
+}
+__device__ __forceinline__ void stage_forward_weights(float* s_w, float* s_b, const Tower& T) {
+  f32x4 v[kFStagePer];
+  int dst[kFStagePer];
+  stage_forward_layer<0>(T, v, dst);
+  stage_forward_layer<1>(T, v, dst);
+  stage_forward_layer<2>(T, v, dst);
+  stage_forward_layer<3>(T, v, dst);
+  static_assert(kBFloats <= kThreads, "one bias element per thread");
+  float bv = 0.0f;
 #pragma unroll
-  for (int i = 0; i < kPer; ++i)
+  for (int l = 0; l < kL; ++l) {
+    const int i = (int)threadIdx.x - b_off(l);
+    if (i >= 0 && i < kN[l] && T.b[l]) bv = T.b[l][i];
+  }
+#pragma unroll
+  for (int i = 0; i < kFStagePer; ++i)
     if (dst[i] >= 0) *reinterpret_cast<f32x4*>(s_w + dst[i]) = v[i];
-#pragma unroll
-  for (int l = 0; l < kL; ++l)
-    for (int i = threadIdx.x; i < blocks(kN[l]) * 16; i += blockDim.x)
-      s_b[b_off(l) + i] = (i < kN[l] && T.b[l]) ? T.b[l][i] : 0.0f;
+  if (threadIdx.x < kBFloats) s_b[threadIdx.x] = bv;
 }
 
 template <int L, int NIN>   // one layer: NIN input blocks in registers -> blocks(kN[L]) output blocks
@@ -151,7 +165,8 @@ ncf16_fwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
   };
   fetch(wave0, xb);
   stage_forward_weights(s_w, s_b, T);
-  for (int i = threadIdx.x; i < kHeadW; i += blockDim.x) s_hw[i] = H.w[i];
+  static_assert(kHeadW <= kThreads, "one head weight per thread");
+  if (threadIdx.x < kHeadW) s_hw[threadIdx.x] = H.w[threadIdx.x];
   __syncthreads();
   const float hc = H.c ? H.c[0] : 0.0f;
   for (int64_t g = wave0; g < groups; g += nwaves) {
@@ -464,7 +479,7 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
     fetch_l0(wave0);
   }
   STAMP(14);
-  for (int i = threadIdx.x; i < kHeadW; i += blockDim.x) s_hw[i] = H.w[i];
+  if (threadIdx.x < kHeadW) s_hw[threadIdx.x] = H.w[threadIdx.x];
   __syncthreads();
   STAMP(1);
 
@@ -759,7 +774,8 @@ int ctr_ncf16_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t*
   const HeadFwd H{head->x, head->ldx, head->w, head->c, head->out, head->ldout, head->act};
   const int64_t groups = ctr_ceil_div(m, 16);
   int64_t grid = ctr_ceil_div(groups, kWaves);
-  if (grid > 256 * 3) grid = 256 * 3;   // three resident workgroups per CU (45 KB of LDS, <= 168 registers)
+  static const int wgs = [] { const char* e = getenv("CTR_NCF16_FWD_WGS"); return e ? atoi(e) : 3; }();
+  if (grid > 256 * wgs) grid = 256 * wgs;   // three resident workgroups per CU (45 KB of LDS, <= 168 registers)
   hipLaunchKernelGGL(ncf16_fwd_kernel, dim3((unsigned)grid), dim3(kThreads), 0, st, T, x, ldx, m, H);
   return ctr_launch_status();
 }
