@@ -1,6 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out/r02
-for w in 3 2 1 4; do
+for w in 3 2; do
 CTR_NCF16_FWD_WGS=$w timeout -k 10 300 python bench.py --no-gather-leg --no-cpu-baseline --steps 50 --warmup 10 > gpurun_out/r02/bench_z.json 2> gpurun_out/r02/bench_z.err || tail -5 gpurun_out/r02/bench_z.err
 python - <<PY
 import json
