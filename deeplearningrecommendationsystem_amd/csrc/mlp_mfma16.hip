@@ -403,13 +403,16 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
   // in s_waitcnt: every wave of the chip issued its burst at the same moment.)
   // Row offsets are 32-bit (the entry point checks m * ld < 2^30 for every operand): one multiply per address in
   // place of a 64-bit product, and the loads take the "scalar base + 32-bit lane offset" form.
-  auto rows_of = [&](int64_t g, uint32_t& rc, bool& live, uint32_t (&rt)[4]) {
+  // the rows of the group being requested: set once per group by rows_for, used by all five fetch_* of that group
+  uint32_t rc = 0, rt[4] = {0, 0, 0, 0};
+  bool rlive = false;
+  auto rows_for = [&](int64_t g) {
 #ifdef CTR_STAMPS_HOT
     g &= 63;   // timing experiment: every wave reads cache-resident rows (results are wrong)
 #endif
     const int64_t row = g * 16 + lo;
-    live = g < groups && row < m;
-    rc = (uint32_t)(live ? row : (m - 1));
+    rlive = g < groups && row < m;
+    rc = (uint32_t)(rlive ? row : (m - 1));
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int64_t r = g * 16 + 4 * q + c;
@@ -421,25 +424,19 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
   };
   const uint32_t ld0 = (uint32_t)T.ldy[0], ld1 = (uint32_t)T.ldy[1], ld2 = (uint32_t)T.ldy[2], ld3 = (uint32_t)T.ldy[3];
   const uint32_t ldx32 = (uint32_t)ldx, ldxe = (uint32_t)H.ldxe;
-  auto fetch_head = [&](int64_t g) {
-    uint32_t rc, rt[4]; bool live;
-    rows_of(g, rc, live, rt);
-    gp = live ? *at(H.gprob, rc, (uint32_t)H.ldgp, 0) : 0.0f;   // a dead lane's gz is zero: it adds nothing anywhere
+  auto fetch_head = [&]() {
+    gp = rlive ? *at(H.gprob, rc, (uint32_t)H.ldgp, 0) : 0.0f;   // a dead lane's gz is zero: it adds nothing anywhere
     pb = *at(H.prob, rc, (uint32_t)H.ldp, 0);
     y4d = q < 2 ? ldg4(at(T.y[3], rc, ld3, 4 * q)) : zero4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) xe[i] = ldg4(at(H.xe, rc, ldxe, 16 * q + 4 * i));
   };
-  auto fetch_l3 = [&](int64_t g) {
-    uint32_t rc, rt[4]; bool live;
-    rows_of(g, rc, live, rt);
+  auto fetch_l3 = [&]() {
     y3d = ldg4(at(T.y[2], rc, ld2, 4 * q));
 #pragma unroll
     for (int c = 0; c < 4; ++c) y3t[c] = *at(T.y[2], rt[c], ld2, lo);
   };
-  auto fetch_l2 = [&](int64_t g) {
-    uint32_t rc, rt[4]; bool live;
-    rows_of(g, rc, live, rt);
+  auto fetch_l2 = [&]() {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       y2d[b] = ldg4(at(T.y[1], rc, ld1, 16 * b + 4 * q));
@@ -447,9 +444,7 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
       for (int c = 0; c < 4; ++c) y2t[b][c] = *at(T.y[1], rt[c], ld1, 16 * b + lo);
     }
   };
-  auto fetch_l1 = [&](int64_t g) {
-    uint32_t rc, rt[4]; bool live;
-    rows_of(g, rc, live, rt);
+  auto fetch_l1 = [&]() {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       y1d[b] = ldg4(at(T.y[0], rc, ld0, 16 * b + 4 * q));
@@ -457,33 +452,14 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
       for (int c = 0; c < 4; ++c) y1t[b][c] = *at(T.y[0], rt[c], ld0, 16 * b + lo);
     }
   };
-  auto fetch_l0 = [&](int64_t g) {
-    uint32_t rc, rt[4]; bool live;
-    rows_of(g, rc, live, rt);
+  auto fetch_l0 = [&]() {
 #pragma unroll
     for (int b = 0; b < 8; ++b)
 #pragma unroll
       for (int c = 0; c < 4; ++c) x0t[b][c] = *at(x, rt[c], ldx32, 16 * b + lo);
   };
   STAMP(0);
-  {
-    f32x4 wv[kStagePer];
-    int wdst[kStagePer];
-    stage_transposed_load(T, wv, wdst);
-    STAMP(12);
-    // (a wave has at most 63 vector-memory operations in flight: with all 84 requested here the issue itself stalled
-    // on the first cold loads for 6 K cycles.  x of the first group is needed last: requested behind the stores.)
-    fetch_head(wave0); fetch_l3(wave0); fetch_l2(wave0); fetch_l1(wave0);
-    STAMP(13);
-    stage_transposed_store(s_wt, wv, wdst);
-    fetch_l0(wave0);
-  }
-  STAMP(14);
-  if (threadIdx.x < kHeadW) s_hw[threadIdx.x] = H.w[threadIdx.x];
-  __syncthreads();
-  STAMP(1);
-
-  // ---- what a lane sums over every group it walks
+  // ---- what a lane sums over every group it walks (zeroed first: 350 moves that then pass under the first loads)
   f32x4 dw0[4][8], dw1[2][4], dw2[2], dw3;                   // dW blocks: register r = row 4q + r, column lo
   f32x4 sb0[4], sb1[2], sb2, sb3;                            // bias sums of this lane's sample: units 4q + r
   f32x4 hy = zero4, hx[4];
@@ -503,6 +479,24 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
     for (int j = 0; j < 4; ++j) dw1[b][j] = zero4;
   }
   sb2 = sb3 = dw3 = zero4;
+  {
+    f32x4 wv[kStagePer];
+    int wdst[kStagePer];
+    stage_transposed_load(T, wv, wdst);
+    STAMP(12);
+    // (a wave has at most 63 vector-memory operations in flight: with all 84 requested here the issue itself stalled
+    // on the first cold loads for 6 K cycles.  x of the first group is needed last: requested behind the stores.)
+    rows_for(wave0);
+    fetch_head(); fetch_l3(); fetch_l2(); fetch_l1();
+    STAMP(13);
+    stage_transposed_store(s_wt, wv, wdst);
+    fetch_l0();
+  }
+  STAMP(14);
+  if (threadIdx.x < kHeadW) s_hw[threadIdx.x] = H.w[threadIdx.x];
+  __syncthreads();
+  STAMP(1);
+
   STAMP(2);
   // ---- the walk.  Per layer: dX products first (their weights stream from LDS, the first pair requested ahead), the
   // next layer's gradient goes to the other tile set, then the dW products cover that LDS round trip.  The operands of
@@ -535,7 +529,8 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
     tiles_put<1>(tA, q, lo, gz3);
     f32x4 w0 = zero4, w1 = zero4;
     dx_first<3>(s_wt, lane, w0, w1);
-    fetch_head(g + nwaves);
+    rows_for(g + nwaves);   // every request from here to the end of this group is for the next one
+    fetch_head();
     // ---- layer 3 (16 -> 8)
     f32x4 gz2[1];
     {
@@ -548,7 +543,7 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
 #pragma unroll
       for (int c = 0; c < 4; ++c) dw3 = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[0][c], y3t[c], dw3, 0, 0, 0);
     }
-    fetch_l3(g + nwaves);
+    fetch_l3();
     // ---- layer 2 (32 -> 16)
     f32x4 gz1[2];
     {
@@ -567,7 +562,7 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
 #pragma unroll
         for (int j = 0; j < 2; ++j) dw2[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[0][c], y2t[j][c], dw2[j], 0, 0, 0);
     }
-    fetch_l2(g + nwaves);
+    fetch_l2();
     // ---- layer 1 (64 -> 32)
     f32x4 gz0[4];
     {
@@ -589,7 +584,7 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
           for (int j = 0; j < 4; ++j)
             dw1[b][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[b][c], y1t[j][c], dw1[b][j], 0, 0, 0);
     }
-    fetch_l1(g + nwaves);
+    fetch_l1();
     // ---- layer 0 (128 -> 64)
     {
       f32x4 tg[4];
@@ -608,7 +603,7 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
           for (int j = 0; j < 8; ++j)
             dw0[b][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[b][c], x0t[j][c], dw0[b][j], 0, 0, 0);
     }
-    fetch_l0(g + nwaves);   // x of the next group: needed last, a whole group from now
+    fetch_l0();   // x of the next group: needed last, a whole group from now
   }
 
   STAMP(8);
