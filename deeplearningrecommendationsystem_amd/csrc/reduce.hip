@@ -8,14 +8,14 @@
 
 namespace {
 
-constexpr int kBlock = 256;
+constexpr int kBlock = 512;
 
 // workgroup = 16 consecutive outputs x 16 part-lanes: lane (o, q) sums every 16th partial of output
 // o with 8 independent loads in flight (256 partials = two rounds of latency; with 4 part-lanes
 // the 64 loads per lane were eight dependent rounds and this pass took 7 us for 12 MB).  A wave
 // holds 4 part-lanes of each output (xor-shuffles 16 and 32), the 4 waves meet in LDS; the order
 // of the sum is fixed.
-constexpr int kOut = 16, kPl = kBlock / kOut;
+constexpr int kOut = 32, kPl = kBlock / kOut;
 
 __global__ void __launch_bounds__(kBlock)
 reduce_segments_kernel(const float* __restrict__ ws, int parts, int64_t stride, const CtrSegments segs) {
@@ -37,12 +37,12 @@ reduce_segments_kernel(const float* __restrict__ ws, int parts, int64_t stride, 
       for (; p < parts; p += kPl) acc[0] += src[(int64_t)p * stride];
     }
     float t = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-    t += __shfl_xor(t, 16, 64);
-    t += __shfl_xor(t, 32, 64);
+    t += __shfl_xor(t, 32, 64);   // a wave holds 2 part-lanes of each of its 32 outputs
     if ((threadIdx.x & 63) < kOut) s_part[wave][o] = t;
     __syncthreads();
     if (threadIdx.x < kOut && e < sg.count)
-      sg.dst[e] += (s_part[0][o] + s_part[1][o]) + (s_part[2][o] + s_part[3][o]);
+      sg.dst[e] += ((s_part[0][o] + s_part[1][o]) + (s_part[2][o] + s_part[3][o])) +
+                   ((s_part[4][o] + s_part[5][o]) + (s_part[6][o] + s_part[7][o]));
     __syncthreads();
   }
 }
