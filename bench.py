@@ -315,6 +315,7 @@ def gather_stage_leg(device, reps: int = 30):
 # label of an event-bracketed call -> the kernel name prefixes it may appear under in the PMC table (first match wins)
 KERNEL_NAMES = {"embed_fwd_fast": ("embed_ids_fast_kernel",), "mlp_fused_bwd": ("ncf16_bwd_kernel", "mlp_bwd_kernel"),
                 "mlp_fused_fwd": ("ncf16_fwd_kernel", "mlp_fwd_direct_kernel", "mlp_fwd_kernel"),
+                "embed_mlp_fused_fwd": ("ncf16_fwd_kernel",),
                 "embed_fwd": ("embed_rows_fast_kernel", "embed_fwd_kernel"),
                 "embed_bwd": ("seg_reduce_kernel", "embed_bwd_kernel"), "mf_fwd": ("mf_fwd_kernel",),
                 "mf_bwd": ("mf_bwd_kernel",)}

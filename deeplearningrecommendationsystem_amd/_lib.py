@@ -15,7 +15,7 @@ import torch  # noqa: F401  (maps libamdhip64 first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTRHIP_LIB", os.path.join(_HERE, "libctrhip.so"))  # env override: A/B builds
-ABI_VERSION = 25
+ABI_VERSION = 26
 DIN_TRIPLE, DIN_PAIR, DIN_H = 0, 1, 2  # layouts of the DIN attention operand (include/ctrhip.h)
 
 CTR_MAX_FIELDS = 32
@@ -121,6 +121,7 @@ SIGNATURES = {
     "ctr_gru_bwd": (_i, [_p, _l, _p, _p, _p, _l, _i, _i, _p, _l, _p, _p, _p]),
     "ctr_mlp_fwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, _p]),
     "ctr_mlp_head_fwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, C.POINTER(MlpHead), _p]),
+    "ctr_embed_mlp_head_fwd": (_i, [C.POINTER(Field), _i, _l, _p, _l, _p, C.POINTER(MlpLayer), _i, C.POINTER(MlpHead), _p]),
     "ctr_mlp_head_bwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, C.POINTER(MlpHeadGrad), _p, _l, _p, _l, _p]),
     "ctr_mlp_bwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, _p, _l, _p, _l, _p, _l, _p]),
     "ctr_negative_sample": (_i, [_p, _l, _l, _l, _i, C.c_uint64, _p, _p, _p, _p]),

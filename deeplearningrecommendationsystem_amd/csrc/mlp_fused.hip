@@ -1756,6 +1756,25 @@ extern "C" int ctr_mlp_head_fwd(const float* x, int64_t ldx, int64_t m, const ct
   return mlp_fwd_impl(x, ldx, m, layers, nlayers, head, stream);
 }
 
+// ctr_embed_fwd(fields -> out) followed by ctr_mlp_head_fwd(out[:, :k0], layers, head) in ONE launch, for the
+// pattern the library has a kernel for (NeuralCF at BASELINE configs[1], mlp_mfma16.hip); CTR_ELIMIT otherwise:
+// nothing was enqueued and the caller issues the two calls.
+extern "C" int ctr_embed_mlp_head_fwd(const ctr_field_t* fields, int nfields, int64_t batch, float* out, int64_t ldo,
+                                      int32_t* err_flag, const ctr_mlp_layer_t* layers, int nlayers,
+                                      const ctr_mlp_head_t* head, void* stream) {
+  CTR_REQUIRE(fields && nfields > 0 && nfields <= CTR_MAX_FIELDS && out && ldo > 0 && layers && nlayers > 0 && head,
+              CTR_EINVAL);
+  CTR_REQUIRE(batch >= 0, CTR_EINVAL);
+  if (batch == 0) return CTR_OK;
+  CTR_REQUIRE(head->w && head->c && head->out && head->ldout >= 1, CTR_EINVAL);
+  CTR_REQUIRE(head->act >= CTR_ACT_NONE && head->act <= CTR_ACT_SIGMOID, CTR_EINVAL);
+  static const bool m16 = [] { const char* e = getenv("CTR_MLP_16"); return !(e && e[0] == '0'); }();
+  if (!m16 || nlayers != 4 || batch < 1024 || !ctr_aligned16(out) || ldo % 4 != 0) return CTR_ELIMIT;
+  for (int l = 0; l < nlayers; ++l)
+    if (!layers[l].w || !layers[l].y || !ctr_aligned16(layers[l].w)) return CTR_ELIMIT;
+  return ctr_ncf16_gather_fwd(fields, nfields, batch, out, ldo, err_flag, layers, head, (hipStream_t)stream);
+}
+
 extern "C" int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
                            const float* gy, int64_t ldgy, float* gx, int64_t ldgx, float* workspace,
                            int64_t workspace_floats, void* stream) {

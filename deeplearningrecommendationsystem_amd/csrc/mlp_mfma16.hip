@@ -96,20 +96,22 @@ __device__ __forceinline__ void stage_forward_layer(const Tower& T, f32x4 (&v)[k
     }
   }
 }
-__device__ __forceinline__ void stage_forward_weights(float* s_w, float* s_b, const Tower& T) {
-  f32x4 v[kFStagePer];
-  int dst[kFStagePer];
+// in two halves (requests, then LDS stores) so that a kernel can put other requests between them
+__device__ __forceinline__ void stage_forward_load(const Tower& T, f32x4 (&v)[kFStagePer], int (&dst)[kFStagePer], float& bv) {
   stage_forward_layer<0>(T, v, dst);
   stage_forward_layer<1>(T, v, dst);
   stage_forward_layer<2>(T, v, dst);
   stage_forward_layer<3>(T, v, dst);
   static_assert(kBFloats <= kThreads, "one bias element per thread");
-  float bv = 0.0f;
+  bv = 0.0f;
 #pragma unroll
   for (int l = 0; l < kL; ++l) {
     const int i = (int)threadIdx.x - b_off(l);
     if (i >= 0 && i < kN[l] && T.b[l]) bv = T.b[l][i];
   }
+}
+__device__ __forceinline__ void stage_forward_store(float* s_w, float* s_b, const f32x4 (&v)[kFStagePer],
+                                                    const int (&dst)[kFStagePer], float bv) {
 #pragma unroll
   for (int i = 0; i < kFStagePer; ++i)
     if (dst[i] >= 0) *reinterpret_cast<f32x4*>(s_w + dst[i]) = v[i];
@@ -146,27 +148,84 @@ __device__ __forceinline__ void layer_fwd(const float* s_w, const float* s_b, in
     for (int r = 0; r < 4; ++r) out[b][r] = fmaxf(out[b][r], 0.0f);
 }
 
+// The embedding stage in front of the tower (NeuralCF: x = [MLP_U[u] | MLP_I[i]], extra columns = GMF_U[u] * GMF_I[i],
+// reference model/neuralcf.py:37-47).  GATHER: the kernel reads the ids and the table rows itself (the tables of the
+// BASELINE shape sit in L2) and writes x and the product into the activation matrix on the way -- the backward and the
+// embedding backward read them there -- instead of reading what a gather kernel wrote a moment earlier.
+struct Gather {
+  const int64_t* uidx; int64_t ustride;
+  const int64_t* iidx; int64_t istride;
+  const float* mlp_u; const float* mlp_i;    // (vocab, 64) each
+  const float* gmf_u; const float* gmf_i;    // (vocab, 64) each
+  int64_t nu, ni;
+  float* xout;                               // (m, ldx): columns 0..127 of the activation matrix
+  float* xeout; int64_t ldxe;                // (m, ldxe): the 64 extra columns
+  int32_t* err_flag;                         // nullable: set on an id outside its table (the row read is row 0)
+};
+
+template <bool GATHER>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))   // <= 168 registers: 3 workgroups per CU
-ncf16_fwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_t m, const HeadFwd H) {
+ncf16_fwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_t m, const HeadFwd H, const Gather G) {
   __shared__ __attribute__((aligned(16))) float s_w[kWFloats];
   __shared__ __attribute__((aligned(16))) float s_b[kBFloats];
   __shared__ __attribute__((aligned(16))) float s_hw[kHeadW];
   const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
   const int64_t groups = (m + 15) / 16;
   const int64_t wave0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * kThreads) >> 6;
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   // the first group's rows are requested before the weights are staged
   f32x4 xb[8], xn[8];
-  auto fetch = [&](int64_t g, f32x4 (&dst)[8]) {
+  f32x4 xeb[4], xen[4];                      // GATHER: the product columns 16q .. 16q+15 of this lane's sample
+  int64_t un = 0, in_ = 0;                   // GATHER: ids of the group after the one being fetched
+  auto fetch_ids = [&](int64_t g) {
+    if constexpr (GATHER) {
+      const int64_t row = g * 16 + n;
+      un = in_ = 0;
+      if (g < groups && row < m) {
+        un = G.uidx[row * G.ustride];
+        in_ = G.iidx[row * G.istride];
+      }
+    }
+  };
+  auto fetch = [&](int64_t g, f32x4 (&dst)[8], f32x4 (&dxe)[4]) {
     const int64_t row = g * 16 + n;
     const bool live = g < groups && row < m;
-    const float* src = x + (live ? row : 0) * ldx + 4 * q;
+    if constexpr (GATHER) {
+      int64_t u = un, i = in_;               // requested a group earlier
+      if (u < 0 || u >= G.nu) { u = 0; if (live && G.err_flag) *G.err_flag = 1; }
+      if (i < 0 || i >= G.ni) { i = 0; if (live && G.err_flag) *G.err_flag = 1; }
+      const float* ru = G.mlp_u + u * 64 + 4 * q;
+      const float* ri = G.mlp_i + i * 64 + 4 * q;
+      const float* pu = G.gmf_u + u * 64 + 16 * q;
+      const float* pi = G.gmf_i + i * 64 + 16 * q;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dst[j] = live ? ldg4(src + 16 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; ++j) {
+        dst[j] = live ? ldg4(ru + 16 * j) : zero4;
+        dst[4 + j] = live ? ldg4(ri + 16 * j) : zero4;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dxe[j] = live ? ldg4(pu + 4 * j) * ldg4(pi + 4 * j) : zero4;
+    } else {
+      const float* src = x + (live ? row : 0) * ldx + 4 * q;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dst[j] = live ? ldg4(src + 16 * j) : zero4;
+    }
   };
-  fetch(wave0, xb);
-  stage_forward_weights(s_w, s_b, T);
-  static_assert(kHeadW <= kThreads, "one head weight per thread");
-  if (threadIdx.x < kHeadW) s_hw[threadIdx.x] = H.w[threadIdx.x];
+  // ids first, the weight requests behind them, then the first group's rows (which wait for the ids alone: loads
+  // return in order), the next group's ids, and only then the LDS stores that wait for the weights
+  fetch_ids(wave0);
+  {
+    f32x4 wv[kFStagePer];
+    int wdst[kFStagePer];
+    float bv;
+    stage_forward_load(T, wv, wdst, bv);
+    const float hw = threadIdx.x < kHeadW ? H.w[threadIdx.x] : 0.0f;
+    fetch(wave0, xb, xeb);
+    fetch_ids(wave0 + nwaves);
+    stage_forward_store(s_w, s_b, wv, wdst, bv);
+    static_assert(kHeadW <= kThreads, "one head weight per thread");
+    if (threadIdx.x < kHeadW) s_hw[threadIdx.x] = hw;
+  }
   __syncthreads();
   const float hc = H.c ? H.c[0] : 0.0f;
   for (int64_t g = wave0; g < groups; g += nwaves) {
@@ -174,9 +233,21 @@ ncf16_fwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
     const bool live = row < m;
     // the head's extra columns of this sample: columns 16q .. 16q+15
     f32x4 xe[4];
+    if constexpr (GATHER) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xe[i] = live ? ldg4(H.x + row * H.ldx + 16 * q + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
-    fetch(g + nwaves, xn);
+      for (int i = 0; i < 4; ++i) xe[i] = xeb[i];
+      if (live) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) stg4(G.xout + row * ldx + 16 * j + 4 * q, xb[j]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stg4(G.xeout + row * G.ldxe + 16 * q + 4 * i, xe[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xe[i] = live ? ldg4(H.x + row * H.ldx + 16 * q + 4 * i) : zero4;
+    }
+    fetch(g + nwaves, xn, xen);
+    fetch_ids(g + 2 * nwaves);
     f32x4 y1[4], y2[2], y3[1], y4[1];
     layer_fwd<0, 8>(s_w, s_b, lane, q, xb, y1);
     if (live) {
@@ -210,6 +281,10 @@ ncf16_fwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
     if (q == 0 && live) H.out[row * H.ldout] = ctr_act(dot + hc, H.act);
 #pragma unroll
     for (int j = 0; j < 8; ++j) xb[j] = xn[j];
+    if constexpr (GATHER) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xeb[i] = xen[i];
+    }
   }
 }
 
@@ -757,8 +832,8 @@ int ctr_ncf16_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t*
 }
 
 // internal entry (mlp_fused.hip dispatches here for the pinned tower + 64-column head); every pointer checked there
-int ctr_ncf16_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, const ctr_mlp_head_t* head,
-                  hipStream_t st) {
+static int ncf16_fwd_launch(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, const ctr_mlp_head_t* head,
+                            const Gather* gather, hipStream_t st) {
   Tower T;
   for (int l = 0; l < kL; ++l) {
     if (layers[l].n != kN[l] || layers[l].k != kK[l] || layers[l].act != CTR_ACT_RELU) return CTR_ELIMIT;
@@ -771,6 +846,37 @@ int ctr_ncf16_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t*
   int64_t grid = ctr_ceil_div(groups, kWaves);
   static const int wgs = [] { const char* e = getenv("CTR_NCF16_FWD_WGS"); return e ? atoi(e) : 3; }();
   if (grid > 256 * wgs) grid = 256 * wgs;   // three resident workgroups per CU (45 KB of LDS, <= 168 registers)
-  hipLaunchKernelGGL(ncf16_fwd_kernel, dim3((unsigned)grid), dim3(kThreads), 0, st, T, x, ldx, m, H);
+  if (gather)
+    hipLaunchKernelGGL(ncf16_fwd_kernel<true>, dim3((unsigned)grid), dim3(kThreads), 0, st, T, x, ldx, m, H, *gather);
+  else
+    hipLaunchKernelGGL(ncf16_fwd_kernel<false>, dim3((unsigned)grid), dim3(kThreads), 0, st, T, x, ldx, m, H, Gather{});
   return ctr_launch_status();
+}
+
+int ctr_ncf16_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, const ctr_mlp_head_t* head,
+                  hipStream_t st) {
+  return ncf16_fwd_launch(x, ldx, m, layers, head, nullptr, st);
+}
+
+// The embedding stage of NeuralCF and its tower in one launch: `fields` must be exactly
+//   [ID_I64 64 -> col 0, ID_I64 64 -> col 64, PROD_I64 64 -> col 128] of one (m, ldo) matrix `out`
+// whose first 128 columns are the tower's input and whose columns 128..191 are the head's extra columns.
+// CTR_ELIMIT: not this pattern (nothing enqueued; the caller runs ctr_embed_fwd + ctr_mlp_head_fwd).
+int ctr_ncf16_gather_fwd(const ctr_field_t* fields, int nfields, int64_t m, float* out, int64_t ldo, int32_t* err_flag,
+                         const ctr_mlp_layer_t* layers, const ctr_mlp_head_t* head, hipStream_t st) {
+  if (nfields != 3) return CTR_ELIMIT;
+  const ctr_field_t &fu = fields[0], &fi = fields[1], &fp = fields[2];
+  const bool pattern = fu.kind == CTR_FIELD_ID_I64 && fi.kind == CTR_FIELD_ID_I64 && fp.kind == CTR_FIELD_PROD_I64 &&
+                       fu.width == 64 && fi.width == 64 && fp.width == 64 && fu.out_col == 0 && fi.out_col == 64 &&
+                       fp.out_col == 128 && fp.idx == fu.idx && fp.idx2 == fi.idx && fp.idx_stride == fu.idx_stride &&
+                       fp.idx_stride == fi.idx_stride && fp.vocab == fu.vocab && fp.vocab2 == fi.vocab && ldo >= 192 &&
+                       head->x == out + 128 && head->ldx == ldo;
+  if (!pattern) return CTR_ELIMIT;
+  const float* tabs[4] = {fu.table, fi.table, fp.table, fp.table2};
+  for (const float* t : tabs)
+    if (!t || !ctr_aligned16(t)) return CTR_ELIMIT;
+  if (!fu.idx || !fi.idx) return CTR_ELIMIT;
+  const Gather G{fu.idx, fu.idx_stride, fi.idx, fi.idx_stride, fu.table, fi.table, fp.table, fp.table2, fu.vocab, fi.vocab,
+                 out, out + 128, ldo, err_flag};
+  return ncf16_fwd_launch(out, ldo, m, layers, head, &G, st);
 }

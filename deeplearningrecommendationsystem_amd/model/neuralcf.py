@@ -18,6 +18,9 @@ from ._base import CtrModule
 # 178.1 us without -- the cross-stream edges of the graph cost more than the 19 us of sort they take off the
 # critical path -- so the default is the single-stream order.
 OVERLAP_SORT = os.environ.get("CTR_NCF_OVERLAP_SORT", "0") == "1"
+# The gather of the four embedding rows inside the tower's forward kernel (ctr_embed_mlp_head_fwd) where the library
+# has that kernel (the BASELINE shape); CTR_NCF_FUSED_GATHER=0 keeps the gather launch + tower launch for A/B.
+FUSED_GATHER = os.environ.get("CTR_NCF_FUSED_GATHER", "1") != "0"
 
 
 class _NeuralCFFunction(torch.autograd.Function):
@@ -53,15 +56,23 @@ class _NeuralCFFunction(torch.autograd.Function):
             sort_ws = ops.new_scratch(buf.device)
             with ops.SideStream(buf.device) as side:
                 ops.embed_bwd_presort(specs, None, batch, buf.stride(0), sort_ws)
-        ops.embed_fwd(specs, None, batch, buf, err_flag)
         wfold, cfold = ops.fold_head_fwd(head_w, mf, proj_w, proj_b, head_b)
-        if n_hidden:
+        acts = None
+        if n_hidden and FUSED_GATHER:
+            # gather + tower + folded head in one launch; None: the library has no such kernel for this shape
+            head = ops.Head(buf[:, l0:l0 + mf], wfold, cfold, ACT_SIGMOID)
+            acts = ops.embed_mlp_head_fwd(specs, batch, buf, l0, hidden, head, buf[:, l0 + mf:], err_flag)
+        if acts is not None:
+            prob = head.out
+        elif n_hidden:
+            ops.embed_fwd(specs, None, batch, buf, err_flag)
             # tower + folded head in one launch: the head's dot product runs on the tile's last
             # activations while they are still in LDS
             head = ops.Head(buf[:, l0:l0 + mf], wfold, cfold, ACT_SIGMOID)
             acts = ops.mlp_fwd(buf[:, :l0], hidden, last_out=buf[:, l0 + mf:], head=head)
             prob = head.out
         else:
+            ops.embed_fwd(specs, None, batch, buf, err_flag)
             # no tower: h is x0 itself, which sits in FRONT of the GMF columns
             acts = [buf[:, :l0]]
             wf = torch.cat([wfold[:, mf:], wfold[:, :mf]], dim=1)

@@ -490,6 +490,39 @@ def mlp_fwd(x: torch.Tensor, layers: Sequence[Layer], last_out: Optional[torch.T
     return acts
 
 
+def embed_mlp_head_fwd(specs: Sequence[FieldSpec], batch: int, buf: torch.Tensor, k0: int, layers: Sequence[Layer],
+                       head: Head, last_out: torch.Tensor, err_flag: Optional[torch.Tensor] = None):
+    """``embed_fwd(specs -> buf)`` and ``mlp_fwd(buf[:, :k0], layers, last_out, head)`` in ONE launch
+    (ctr_embed_mlp_head_fwd) where the library has a kernel for the pattern (NeuralCF at BASELINE configs[1]); returns
+    the activation list of ``mlp_fwd`` or None when it refused (nothing was enqueued: issue the two calls)."""
+    buf = _mat(buf, "buf")
+    x = buf[:, :k0]
+    if not _fusable(x, layers) or head.x_extra is None:
+        return None
+    m = batch
+    ys = [torch.empty((m, layer.weight.shape[0]), dtype=torch.float32, device=buf.device) for layer in layers[:-1]]
+    ys.append(last_out)
+    arr = _mlp_layer_array(layers, ys)
+    farr = _field_array(specs)
+    dims = [(layer.weight.shape[0], layer.weight.shape[1]) for layer in layers]
+    p = head.x_extra.shape[1]
+    out = torch.empty((m, 1), dtype=torch.float32, device=buf.device)
+    hd = _lib.MlpHead(_lib.ptr(head.x_extra), _ld(head.x_extra), head.w.data_ptr(), head.c.data_ptr(), out.data_ptr(), 1, p,
+                      head.act)
+    rc = _timed("embed_mlp_fused_fwd",
+                lambda: (_embed_bytes(specs, batch, False) + 4 * m * (1 + sum(n for n, _ in dims)),
+                         2 * m * (sum(n * k for n, k in dims) + p + dims[-1][0])),
+                _lib.load().ctr_embed_mlp_head_fwd, farr, len(specs), batch, buf.data_ptr(), _ld(buf), _lib.ptr(err_flag), arr,
+                len(layers), C.byref(hd), _lib.stream_ptr())
+    if rc in _REFUSED:
+        if _profiler is not None and _profiler.records and _profiler.records[-1][0] == "embed_mlp_fused_fwd":
+            _profiler.records.pop()  # refused: nothing ran
+        return None
+    _lib.check(rc, "ctr_embed_mlp_head_fwd")
+    head.out = out
+    return [x] + ys
+
+
 def _head_unfused(head: Optional[Head], y_last: torch.Tensor) -> None:
     if head is None:
         return

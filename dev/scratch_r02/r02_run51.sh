@@ -1,6 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out/r02
-timeout -k 10 900 python -m pytest tests/test_gpu_ops.py -q -m gpu -x 2>&1 | tail -3 &&
+timeout -k 10 900 python -m pytest tests/test_gpu_ops.py -q -m gpu -x -k "mlp or reduce or linear" 2>&1 | tail -3 &&
 for v in 1 2; do
 timeout -k 10 300 python bench.py --no-gather-leg --no-cpu-baseline --steps 100 --warmup 10 > gpurun_out/r02/bench_z.json 2> gpurun_out/r02/bench_z.err || tail -5 gpurun_out/r02/bench_z.err
 python - <<PY

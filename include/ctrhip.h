@@ -376,6 +376,17 @@ typedef struct ctr_mlp_head {
 } ctr_mlp_head_t;
 int ctr_mlp_head_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
                      const ctr_mlp_head_t* head, void* stream);
+/* The embedding stage and the stack behind it in one launch: the effect of
+ *   ctr_embed_fwd(fields, nfields, NULL, 0, batch, out, ldo, err_flag)  followed by
+ *   ctr_mlp_head_fwd(out, ldo, batch, layers, nlayers, head)            with head->x inside `out`,
+ * for the pattern the library has a kernel for -- NeuralCF at BASELINE configs[1] (model/neuralcf.py:37-56:
+ * fields = [ID_I64 64 -> column 0, ID_I64 64 -> column 64, PROD_I64 64 -> column 128] of one matrix, the pinned
+ * 128-64-32-16-8 ReLU tower on columns 0..127, head->x = out + 128, p = 64).  The kernel reads the ids and table rows
+ * itself and writes the gathered columns into `out` on the way (the backward passes read them there).  Any other
+ * shape: CTR_ELIMIT, nothing enqueued -- issue the two calls. */
+int ctr_embed_mlp_head_fwd(const ctr_field_t* fields, int nfields, int64_t batch, float* out, int64_t ldo,
+                           int32_t* err_flag /*nullable*/, const ctr_mlp_layer_t* layers, int nlayers,
+                           const ctr_mlp_head_t* head, void* stream);
 /* Backward of ctr_mlp_head_fwd in ONE launch with the stack's backward: per row gz = gprob * act'(prob);
  * the stack's gY is gz * w[p:] (never stored), gx_extra[row, 0:p] = gz * w[0:p] is written, and
  * gw[0:p+n_last] += sum_rows gz * [x_extra | y_last],  gc[0] += sum_rows gz.  Layers' gw / gb and gx as in

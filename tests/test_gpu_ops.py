@@ -434,6 +434,51 @@ def test_mlp_backward_with_fused_head_matches_autograd(ops, m):
         torch.testing.assert_close(gb.cpu(), rb.grad.float(), rtol=1e-5, atol=2e-6 * scale)
 
 
+@pytest.mark.parametrize("m", [4096, 1037, 70001])
+def test_gather_inside_the_tower_forward_matches_the_two_launches(ops, m):
+    """ctr_embed_mlp_head_fwd (NeuralCF at BASELINE configs[1]: ids -> four table rows -> tower -> folded head in one
+    launch) against ctr_embed_fwd + ctr_mlp_head_fwd: the gathered columns bit for bit, activations and probabilities
+    within the forward tolerance; one id outside its table raises the flag and reads row 0, as the gather kernel does"""
+    from deeplearningrecommendationsystem_amd._lib import FIELD_ID_I64, FIELD_PROD_I64
+    g = torch.Generator().manual_seed(m)
+    nu, ni, half, mf = 943, 1682, 64, 64
+    dims = [128, 64, 32, 16, 8]
+    tabs = [torch.randn(v, 64, generator=g).to(DEV) for v in (nu, ni, nu, ni)]   # mlp_u, mlp_i, gmf_u, gmf_i
+    u = torch.randint(0, nu, (m,), generator=g)
+    i = torch.randint(0, ni, (m,), generator=g)
+    u[5] = nu + 3                                     # outside the table
+    u, i = u.to(DEV), i.to(DEV)
+    layers = [ops.Layer((torch.randn(n, k, generator=g) / k ** 0.5).to(DEV), (torch.randn(n, generator=g) * 0.1).to(DEV), 1)
+              for k, n in zip(dims[:-1], dims[1:])]
+    w = (torch.randn(1, mf + dims[-1], generator=g) * 0.3).to(DEV)
+    c = torch.randn(1, generator=g).to(DEV)
+    specs = [ops.FieldSpec(FIELD_ID_I64, half, 0, table=tabs[0], idx=u),
+             ops.FieldSpec(FIELD_ID_I64, half, half, table=tabs[1], idx=i),
+             ops.FieldSpec(FIELD_PROD_I64, mf, 2 * half, table=tabs[2], idx=u, table2=tabs[3], idx2=i)]
+    width = 2 * half + mf + dims[-1]
+
+    def run(fused):
+        buf = torch.full((m, width), float("nan"), device=DEV)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        head = ops.Head(buf[:, 128:192], w, c, 2)
+        if fused:
+            acts = ops.embed_mlp_head_fwd(specs, m, buf, 128, layers, head, buf[:, 192:], flag)
+            assert acts is not None, "the BASELINE pattern must take the fused launch"
+        else:
+            ops.embed_fwd(specs, None, m, buf, flag)
+            acts = ops.mlp_fwd(buf[:, :128], layers, last_out=buf[:, 192:], head=head)
+        return buf, acts, head.out, flag
+
+    bf, af, pf, ff = run(True)
+    bs, as_, ps, fs = run(False)
+    assert int(ff.item()) == 1 and int(fs.item()) == 1
+    assert torch.equal(bf[:, :192].cpu(), bs[:, :192].cpu())
+    for a, b in zip(af[1:], as_[1:]):
+        torch.testing.assert_close(a.cpu(), b.cpu(), rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(pf.cpu(), ps.cpu(), rtol=1e-5, atol=2e-6)
+    assert not torch.isnan(bf).any()
+
+
 def test_tiled_tower_kernels_behind_the_switch():
     """CTR_MLP_16=0 selects the tiled fused-MLP kernels for the pinned NeuralCF tower (the A/B partner of the
     operand-layout kernels, read once per process): the same parity cases in one child process"""
