@@ -1760,7 +1760,7 @@ extern "C" int ctr_mlp_head_fwd(const float* x, int64_t ldx, int64_t m, const ct
 // pattern the library has a kernel for (NeuralCF at BASELINE configs[1], mlp_mfma16.hip); CTR_ELIMIT otherwise:
 // nothing was enqueued and the caller issues the two calls.
 extern "C" int ctr_embed_mlp_head_fwd(const ctr_field_t* fields, int nfields, int64_t batch, float* out, int64_t ldo,
-                                      int32_t* err_flag, const ctr_mlp_layer_t* layers, int nlayers,
+                                      int32_t* err_flag, int write_x, const ctr_mlp_layer_t* layers, int nlayers,
                                       const ctr_mlp_head_t* head, void* stream) {
   CTR_REQUIRE(fields && nfields > 0 && nfields <= CTR_MAX_FIELDS && out && ldo > 0 && layers && nlayers > 0 && head,
               CTR_EINVAL);
@@ -1772,7 +1772,7 @@ extern "C" int ctr_embed_mlp_head_fwd(const ctr_field_t* fields, int nfields, in
   if (!m16 || nlayers != 4 || batch < 1024 || !ctr_aligned16(out) || ldo % 4 != 0) return CTR_ELIMIT;
   for (int l = 0; l < nlayers; ++l)
     if (!layers[l].w || !layers[l].y || !ctr_aligned16(layers[l].w)) return CTR_ELIMIT;
-  return ctr_ncf16_gather_fwd(fields, nfields, batch, out, ldo, err_flag, layers, head, (hipStream_t)stream);
+  return ctr_ncf16_gather_fwd(fields, nfields, batch, out, ldo, err_flag, write_x, layers, head, (hipStream_t)stream);
 }
 
 extern "C" int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
@@ -1829,9 +1829,11 @@ extern "C" int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp
   return ctr_reduce_segments(workspace, (int)grid, b.slab, segs, st);
 }
 
-extern "C" int ctr_mlp_head_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
-                                const ctr_mlp_head_grad_t* hg, float* gx, int64_t ldgx, float* workspace,
-                                int64_t workspace_floats, void* stream) {
+// fields != NULL: the stack's input is gathered from the fields' tables (ctr_embed_mlp_head_bwd); x then only stands for
+// "the matrix the forward wrote the other columns into" and is not read
+static int mlp_head_bwd_impl(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t m,
+                             const ctr_mlp_layer_t* layers, int nlayers, const ctr_mlp_head_grad_t* hg, float* gx,
+                             int64_t ldgx, float* workspace, int64_t workspace_floats, void* stream) {
   CTR_REQUIRE(m >= 0 && hg, CTR_EINVAL);
   if (m == 0) return CTR_OK;
   CTR_REQUIRE(x && workspace, CTR_EINVAL);
@@ -1861,7 +1863,8 @@ extern "C" int ctr_mlp_head_bwd(const float* x, int64_t ldx, int64_t m, const ct
   bool done16 = false;
   if (m16 && gx && slab == ctr_ncf16_slab_floats()) {
     int g16 = 0;
-    rc = ctr_ncf16_bwd(x, ldx, m, layers, hg, gx, ldgx, workspace, workspace_floats, &g16, st);
+    rc = fields ? ctr_ncf16_gather_bwd(fields, nfields, m, layers, hg, gx, ldgx, workspace, workspace_floats, &g16, st)
+                : ctr_ncf16_bwd(x, ldx, m, layers, hg, gx, ldgx, workspace, workspace_floats, &g16, st);
     if (rc == CTR_OK) {
       grid = g16;
       done16 = true;
@@ -1869,6 +1872,7 @@ extern "C" int ctr_mlp_head_bwd(const float* x, int64_t ldx, int64_t m, const ct
       return rc;
     }
   }
+  if (fields && !done16) return CTR_ELIMIT;   // only the operand-layout kernel gathers
   const HeadBwdDesc hb{hg->gprob, hg->ldgprob, hg->prob, hg->ldprob, hg->x, hg->ldx, hg->w, hg->gx, hg->ldgx, hg->act};
   // CTR_MLP_PAIR=1 selects the two-waves-per-tile kernel (A/B switch).  Measured on MI355X, batch 65536 (rocprofv3,
   // profiles/r02_mlp_pair_ab.txt): 73.1 us against 72.3 us for the one-wave-per-tile kernel -- occupancy 2, 201
@@ -1920,4 +1924,20 @@ extern "C" int ctr_mlp_head_bwd(const float* x, int64_t ldx, int64_t m, const ct
   segs.s[segs.n++] = CtrSegment{off, kHeadBwdP + kHeadBwdN, hg->gw};
   segs.s[segs.n++] = CtrSegment{off + kHeadBwdP + kHeadBwdN, 1, hg->gc};
   return ctr_reduce_segments(workspace, (int)grid, slab, segs, st);
+}
+
+extern "C" int ctr_mlp_head_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
+                                const ctr_mlp_head_grad_t* hg, float* gx, int64_t ldgx, float* workspace,
+                                int64_t workspace_floats, void* stream) {
+  return mlp_head_bwd_impl(nullptr, 0, x, ldx, m, layers, nlayers, hg, gx, ldgx, workspace, workspace_floats, stream);
+}
+
+// Backward of ctr_embed_mlp_head_fwd(..., write_x = 0, ...): as ctr_mlp_head_bwd, with the stack's input gathered again
+// from the fields' tables by the samples' ids instead of read from memory.  CTR_ELIMIT: not the pattern.
+extern "C" int ctr_embed_mlp_head_bwd(const ctr_field_t* fields, int nfields, int64_t batch, const ctr_mlp_layer_t* layers,
+                                      int nlayers, const ctr_mlp_head_grad_t* hg, float* gx, int64_t ldgx,
+                                      float* workspace, int64_t workspace_floats, void* stream) {
+  CTR_REQUIRE(fields && nfields > 0 && nfields <= CTR_MAX_FIELDS && hg, CTR_EINVAL);
+  return mlp_head_bwd_impl(fields, nfields, hg->x, hg->ldx, batch, layers, nlayers, hg, gx, ldgx, workspace,
+                           workspace_floats, stream);
 }

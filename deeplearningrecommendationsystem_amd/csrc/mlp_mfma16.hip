@@ -161,6 +161,7 @@ struct Gather {
   float* xout;                               // (m, ldx): columns 0..127 of the activation matrix
   float* xeout; int64_t ldxe;                // (m, ldxe): the 64 extra columns
   int32_t* err_flag;                         // nullable: set on an id outside its table (the row read is row 0)
+  int write_x;                               // forward: 0 = the backward gathers x again (ctr_embed_mlp_head_bwd), x is not written
 };
 
 template <bool GATHER>
@@ -237,8 +238,10 @@ ncf16_fwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
 #pragma unroll
       for (int i = 0; i < 4; ++i) xe[i] = xeb[i];
       if (live) {
+        if (G.write_x) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) stg4(G.xout + row * ldx + 16 * j + 4 * q, xb[j]);
+          for (int j = 0; j < 8; ++j) stg4(G.xout + row * ldx + 16 * j + 4 * q, xb[j]);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) stg4(G.xeout + row * G.ldxe + 16 * q + 4 * i, xe[i]);
       }
@@ -456,9 +459,12 @@ __device__ unsigned long long g_stamps[4 * 16];
 #define STAMP(i) do {} while (0)
 #endif
 
+// GATHER: the tower's input is not read from memory but gathered again from the two MLP tables by the samples' ids
+// (the forward then never wrote it: 33 MB less to write there, 33 MB less to read here; the tables sit in L2).
+template <bool GATHER>
 __global__ void __launch_bounds__(kThreads)
 ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_t m, const HeadBwd H,
-                 float* __restrict__ gx, int64_t ldgx, float* __restrict__ ws) {
+                 float* __restrict__ gx, int64_t ldgx, float* __restrict__ ws, const Gather G) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ __attribute__((aligned(16))) float s_hw[kHeadW];
   float* s_wt = lds;
@@ -480,6 +486,7 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
   // place of a 64-bit product, and the loads take the "scalar base + 32-bit lane offset" form.
   // the rows of the group being requested: set once per group by rows_for, used by all five fetch_* of that group
   uint32_t rc = 0, rt[4] = {0, 0, 0, 0};
+  uint32_t uo[4] = {0, 0, 0, 0}, io[4] = {0, 0, 0, 0};
   bool rlive = false;
   auto rows_for = [&](int64_t g) {
 #ifdef CTR_STAMPS_HOT
@@ -492,6 +499,18 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
     for (int c = 0; c < 4; ++c) {
       const int64_t r = g * 16 + 4 * q + c;
       rt[c] = (uint32_t)((g >= groups || r >= m) ? (m - 1) : r);   // (a clamped row meets a zero gradient)
+    }
+    if constexpr (GATHER) {
+      // byte offsets of the four samples' rows in the two tables (ids outside a table read row 0, as in the forward);
+      // requested at the head of a group, used by fetch_l0 at its end
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        int64_t u = G.uidx[(int64_t)rt[c] * G.ustride], i = G.iidx[(int64_t)rt[c] * G.istride];
+        if (u < 0 || u >= G.nu) u = 0;
+        if (i < 0 || i >= G.ni) i = 0;
+        uo[c] = (uint32_t)u * 256u;
+        io[c] = (uint32_t)i * 256u;
+      }
     }
   };
   auto at = [](const float* base, uint32_t row, uint32_t ld, uint32_t col) {
@@ -531,7 +550,13 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
 #pragma unroll
     for (int b = 0; b < 8; ++b)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) x0t[b][c] = *at(x, rt[c], ldx32, 16 * b + lo);
+      for (int c = 0; c < 4; ++c) {
+        if constexpr (GATHER)
+          x0t[b][c] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(b < 4 ? G.mlp_u : G.mlp_i) +
+                                                     ((b < 4 ? uo[c] : io[c]) + (16 * (b & 3) + lo) * 4u));
+        else
+          x0t[b][c] = *at(x, rt[c], ldx32, 16 * b + lo);
+      }
   };
   STAMP(0);
   // ---- what a lane sums over every group it walks (zeroed first: 350 moves that then pass under the first loads)
@@ -799,8 +824,9 @@ extern "C" __attribute__((visibility("default"))) int ctr_ncf16_debug_stamps(uns
 }
 #endif
 
-int ctr_ncf16_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, const ctr_mlp_head_grad_t* hg,
-                  float* gx, int64_t ldgx, float* workspace, int64_t workspace_floats, int* grid_out, hipStream_t st) {
+static int ncf16_bwd_launch(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, const ctr_mlp_head_grad_t* hg,
+                            float* gx, int64_t ldgx, float* workspace, int64_t workspace_floats, int* grid_out,
+                            const Gather* gather, hipStream_t st) {
   Tower T;
   for (int l = 0; l < kL; ++l) {
     if (layers[l].n != kN[l] || layers[l].k != kK[l] || layers[l].act != CTR_ACT_RELU) return CTR_ELIMIT;
@@ -821,14 +847,51 @@ int ctr_ncf16_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t*
   if (grid > 256) grid = 256;   // 172 accumulator registers per lane: one wave per SIMD, one workgroup per CU
   if (workspace_floats < grid * kSlab) return CTR_ELIMIT;
   const size_t lds_bytes = sizeof(float) * kBwdLds;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(ncf16_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds_bytes) != hipSuccess)
-    return CTR_ELAUNCH;
+  const void* kern = gather ? reinterpret_cast<const void*>(ncf16_bwd_kernel<true>)
+                             : reinterpret_cast<const void*>(ncf16_bwd_kernel<false>);
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return CTR_ELAUNCH;
   const HeadBwd H{hg->gprob, hg->ldgprob, hg->prob, hg->ldprob, hg->x, hg->ldx, hg->w, hg->gx, hg->ldgx, hg->act};
-  hipLaunchKernelGGL(ncf16_bwd_kernel, dim3((unsigned)grid), dim3(kThreads), lds_bytes, st, T, x, ldx, m, H, gx, ldgx,
-                     workspace);
+  if (gather)
+    hipLaunchKernelGGL(ncf16_bwd_kernel<true>, dim3((unsigned)grid), dim3(kThreads), lds_bytes, st, T, x, ldx, m, H, gx, ldgx,
+                       workspace, *gather);
+  else
+    hipLaunchKernelGGL(ncf16_bwd_kernel<false>, dim3((unsigned)grid), dim3(kThreads), lds_bytes, st, T, x, ldx, m, H, gx,
+                       ldgx, workspace, Gather{});
   *grid_out = (int)grid;
   return ctr_launch_status();
+}
+
+int ctr_ncf16_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, const ctr_mlp_head_grad_t* hg,
+                  float* gx, int64_t ldgx, float* workspace, int64_t workspace_floats, int* grid_out, hipStream_t st) {
+  return ncf16_bwd_launch(x, ldx, m, layers, hg, gx, ldgx, workspace, workspace_floats, grid_out, nullptr, st);
+}
+
+// the NeuralCF field pattern of ctr_ncf16_gather_fwd (x = [MLP_U[u] | MLP_I[i]]); false: not that pattern
+static bool ncf_pattern(const ctr_field_t* fields, int nfields, Gather* G) {
+  if (nfields != 3) return false;
+  const ctr_field_t &fu = fields[0], &fi = fields[1], &fp = fields[2];
+  const bool pattern = fu.kind == CTR_FIELD_ID_I64 && fi.kind == CTR_FIELD_ID_I64 && fp.kind == CTR_FIELD_PROD_I64 &&
+                       fu.width == 64 && fi.width == 64 && fp.width == 64 && fu.out_col == 0 && fi.out_col == 64 &&
+                       fp.out_col == 128 && fp.idx == fu.idx && fp.idx2 == fi.idx && fp.idx_stride == fu.idx_stride &&
+                       fp.idx_stride == fi.idx_stride && fp.vocab == fu.vocab && fp.vocab2 == fi.vocab &&
+                       fu.vocab < (1 << 24) && fi.vocab < (1 << 24);   // 32-bit byte offsets of 256-byte rows
+  if (!pattern || !fu.idx || !fi.idx) return false;
+  const float* tabs[4] = {fu.table, fi.table, fp.table, fp.table2};
+  for (const float* t : tabs)
+    if (!t || !ctr_aligned16(t)) return false;
+  *G = Gather{fu.idx, fu.idx_stride, fi.idx, fi.idx_stride, fu.table, fi.table, fp.table, fp.table2, fu.vocab, fi.vocab,
+              nullptr, nullptr, 0, nullptr, 1};
+  return true;
+}
+
+// ctr_ncf16_bwd with the tower's input gathered from the tables (see ncf16_bwd_kernel<true>); x / ldx only describe
+// the row stride the forward used for the other columns and are not read
+int ctr_ncf16_gather_bwd(const ctr_field_t* fields, int nfields, int64_t m, const ctr_mlp_layer_t* layers,
+                         const ctr_mlp_head_grad_t* hg, float* gx, int64_t ldgx, float* workspace,
+                         int64_t workspace_floats, int* grid_out, hipStream_t st) {
+  Gather G;
+  if (!ncf_pattern(fields, nfields, &G)) return CTR_ELIMIT;
+  return ncf16_bwd_launch(hg->x, hg->ldx, m, layers, hg, gx, ldgx, workspace, workspace_floats, grid_out, &G, st);
 }
 
 // internal entry (mlp_fused.hip dispatches here for the pinned tower + 64-column head); every pointer checked there
@@ -863,20 +926,13 @@ int ctr_ncf16_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t*
 // whose first 128 columns are the tower's input and whose columns 128..191 are the head's extra columns.
 // CTR_ELIMIT: not this pattern (nothing enqueued; the caller runs ctr_embed_fwd + ctr_mlp_head_fwd).
 int ctr_ncf16_gather_fwd(const ctr_field_t* fields, int nfields, int64_t m, float* out, int64_t ldo, int32_t* err_flag,
-                         const ctr_mlp_layer_t* layers, const ctr_mlp_head_t* head, hipStream_t st) {
-  if (nfields != 3) return CTR_ELIMIT;
-  const ctr_field_t &fu = fields[0], &fi = fields[1], &fp = fields[2];
-  const bool pattern = fu.kind == CTR_FIELD_ID_I64 && fi.kind == CTR_FIELD_ID_I64 && fp.kind == CTR_FIELD_PROD_I64 &&
-                       fu.width == 64 && fi.width == 64 && fp.width == 64 && fu.out_col == 0 && fi.out_col == 64 &&
-                       fp.out_col == 128 && fp.idx == fu.idx && fp.idx2 == fi.idx && fp.idx_stride == fu.idx_stride &&
-                       fp.idx_stride == fi.idx_stride && fp.vocab == fu.vocab && fp.vocab2 == fi.vocab && ldo >= 192 &&
-                       head->x == out + 128 && head->ldx == ldo;
-  if (!pattern) return CTR_ELIMIT;
-  const float* tabs[4] = {fu.table, fi.table, fp.table, fp.table2};
-  for (const float* t : tabs)
-    if (!t || !ctr_aligned16(t)) return CTR_ELIMIT;
-  if (!fu.idx || !fi.idx) return CTR_ELIMIT;
-  const Gather G{fu.idx, fu.idx_stride, fi.idx, fi.idx_stride, fu.table, fi.table, fp.table, fp.table2, fu.vocab, fi.vocab,
-                 out, out + 128, ldo, err_flag};
+                         int write_x, const ctr_mlp_layer_t* layers, const ctr_mlp_head_t* head, hipStream_t st) {
+  Gather G;
+  if (!ncf_pattern(fields, nfields, &G) || ldo < 192 || head->x != out + 128 || head->ldx != ldo) return CTR_ELIMIT;
+  G.xout = out;
+  G.xeout = out + 128;
+  G.ldxe = ldo;
+  G.err_flag = err_flag;
+  G.write_x = write_x;
   return ncf16_fwd_launch(out, ldo, m, layers, head, &G, st);
 }

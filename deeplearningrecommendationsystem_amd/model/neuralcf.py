@@ -21,6 +21,10 @@ OVERLAP_SORT = os.environ.get("CTR_NCF_OVERLAP_SORT", "0") == "1"
 # The gather of the four embedding rows inside the tower's forward kernel (ctr_embed_mlp_head_fwd) where the library
 # has that kernel (the BASELINE shape); CTR_NCF_FUSED_GATHER=0 keeps the gather launch + tower launch for A/B.
 FUSED_GATHER = os.environ.get("CTR_NCF_FUSED_GATHER", "1") != "0"
+# ... and gathered AGAIN by the tower's backward kernel (ctr_embed_mlp_head_bwd), so that the forward never writes the
+# (B, 128) tower input and the backward never reads it (the tables of the BASELINE shape sit in L2);
+# CTR_NCF_REGATHER=0: the forward writes it, the backward reads it.
+REGATHER = os.environ.get("CTR_NCF_REGATHER", "1") != "0"
 
 
 class _NeuralCFFunction(torch.autograd.Function):
@@ -61,7 +65,10 @@ class _NeuralCFFunction(torch.autograd.Function):
         if n_hidden and FUSED_GATHER:
             # gather + tower + folded head in one launch; None: the library has no such kernel for this shape
             head = ops.Head(buf[:, l0:l0 + mf], wfold, cfold, ACT_SIGMOID)
-            acts = ops.embed_mlp_head_fwd(specs, batch, buf, l0, hidden, head, buf[:, l0 + mf:], err_flag)
+            regather = REGATHER and any(ctx.needs_input_grad[4:])
+            acts = ops.embed_mlp_head_fwd(specs, batch, buf, l0, hidden, head, buf[:, l0 + mf:], err_flag,
+                                          write_x=not regather)
+            ctx.regather = regather and acts is not None
         if acts is not None:
             prob = head.out
         elif n_hidden:
@@ -78,6 +85,8 @@ class _NeuralCFFunction(torch.autograd.Function):
             wf = torch.cat([wfold[:, mf:], wfold[:, :mf]], dim=1)
             prob = ops.linear_fwd(buf, wf, cfold, ACT_SIGMOID)
         ctx.n_hidden = n_hidden
+        if not hasattr(ctx, "regather"):
+            ctx.regather = False
         ctx.sort_ws, ctx.sort_side = sort_ws, side
         ctx.save_for_backward(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i, buf, prob, wfold, *acts[1:-1], *dense)
         return prob
@@ -106,7 +115,9 @@ class _NeuralCFFunction(torch.autograd.Function):
             # head backward + tower backward in one launch where the library has it (the BASELINE tower) ...
             head = ops.Head(buf[:, l0:l0 + mf], wfold, None, ACT_SIGMOID)
             layer_grads = ops.mlp_head_bwd(acts, hidden, head, prob, gprob.contiguous(), gbuf[:, l0:l0 + mf], gwfold,
-                                           gcfold, gbuf[:, :l0], zeros)
+                                           gcfold, gbuf[:, :l0], zeros,
+                                           gather_specs=_specs(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i)
+                                           if ctx.regather else None)
             if layer_grads is None:
                 # ... else the head as a single-unit layer on [gmf | h], then the tower
                 ops.linear_bwd(buf[:, l0:], wfold, prob, gprob.contiguous(), ACT_SIGMOID, gbuf[:, l0:], gwfold, gcfold)

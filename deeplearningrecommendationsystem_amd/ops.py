@@ -491,10 +491,11 @@ def mlp_fwd(x: torch.Tensor, layers: Sequence[Layer], last_out: Optional[torch.T
 
 
 def embed_mlp_head_fwd(specs: Sequence[FieldSpec], batch: int, buf: torch.Tensor, k0: int, layers: Sequence[Layer],
-                       head: Head, last_out: torch.Tensor, err_flag: Optional[torch.Tensor] = None):
+                       head: Head, last_out: torch.Tensor, err_flag: Optional[torch.Tensor] = None, write_x: bool = True):
     """``embed_fwd(specs -> buf)`` and ``mlp_fwd(buf[:, :k0], layers, last_out, head)`` in ONE launch
     (ctr_embed_mlp_head_fwd) where the library has a kernel for the pattern (NeuralCF at BASELINE configs[1]); returns
-    the activation list of ``mlp_fwd`` or None when it refused (nothing was enqueued: issue the two calls)."""
+    the activation list of ``mlp_fwd`` or None when it refused (nothing was enqueued: issue the two calls).
+    ``write_x=False``: ``buf[:, :k0]`` is left untouched and the backward has to be ``embed_mlp_head_bwd``."""
     buf = _mat(buf, "buf")
     x = buf[:, :k0]
     if not _fusable(x, layers) or head.x_extra is None:
@@ -512,8 +513,8 @@ def embed_mlp_head_fwd(specs: Sequence[FieldSpec], batch: int, buf: torch.Tensor
     rc = _timed("embed_mlp_fused_fwd",
                 lambda: (_embed_bytes(specs, batch, False) + 4 * m * (1 + sum(n for n, _ in dims)),
                          2 * m * (sum(n * k for n, k in dims) + p + dims[-1][0])),
-                _lib.load().ctr_embed_mlp_head_fwd, farr, len(specs), batch, buf.data_ptr(), _ld(buf), _lib.ptr(err_flag), arr,
-                len(layers), C.byref(hd), _lib.stream_ptr())
+                _lib.load().ctr_embed_mlp_head_fwd, farr, len(specs), batch, buf.data_ptr(), _ld(buf), _lib.ptr(err_flag),
+                1 if write_x else 0, arr, len(layers), C.byref(hd), _lib.stream_ptr())
     if rc in _REFUSED:
         if _profiler is not None and _profiler.records and _profiler.records[-1][0] == "embed_mlp_fused_fwd":
             _profiler.records.pop()  # refused: nothing ran
@@ -540,7 +541,7 @@ def _head_unfused(head: Optional[Head], y_last: torch.Tensor) -> None:
 
 def mlp_head_bwd(acts: Sequence[torch.Tensor], layers: Sequence[Layer], head: Head, prob: torch.Tensor,
                  gprob: torch.Tensor, g_extra: torch.Tensor, gw_head: torch.Tensor, gc_head: torch.Tensor,
-                 gx_first: torch.Tensor, zeros: dict):
+                 gx_first: torch.Tensor, zeros: dict, gather_specs: Optional[Sequence[FieldSpec]] = None):
     """backward of ``mlp_fwd(..., head=head)`` in one launch (ctr_mlp_head_bwd): the head's gz, the stack's
     backward, ``g_extra = gz * w[:p]`` and the head's weight / bias sums.  Returns the per-layer
     ``[(gw, gb)]`` or None when the library has no fused path for this stack (nothing was enqueued)."""
@@ -557,13 +558,19 @@ def mlp_head_bwd(acts: Sequence[torch.Tensor], layers: Sequence[Layer], head: He
     hg = _lib.MlpHeadGrad(prob.data_ptr(), prob.stride(0), gprob.data_ptr(), gprob.stride(0), head.x_extra.data_ptr(),
                           _ld(head.x_extra), head.w.data_ptr(), g_extra.data_ptr(), _ld(g_extra), gw_head.data_ptr(),
                           gc_head.data_ptr(), p, head.act)
-    rc = _timed("mlp_fused_bwd",
-                # read: stack input, every saved activation, the extra columns, prob, gprob; written: gX, g_extra.
-                # flops: dW + dX of every layer, the head's products and sums
-                lambda: (4 * m * (2 * dims[0][1] + sum(n for n, _ in dims) + 2 * p + 2),
-                         4 * m * (sum(n * k for n, k in dims) + p + dims[-1][0])),
-                _lib.load().ctr_mlp_head_bwd, x0.data_ptr(), _ld(x0), m, arr, len(layers), C.byref(hg),
-                gx_first.data_ptr(), _ld(gx_first), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+    meta = lambda: (4 * m * (2 * dims[0][1] + sum(n for n, _ in dims) + 2 * p + 2),  # noqa: E731
+                    4 * m * (sum(n * k for n, k in dims) + p + dims[-1][0]))
+    # read: stack input, every saved activation, the extra columns, prob, gprob; written: gX, g_extra.
+    # flops: dW + dX of every layer, the head's products and sums
+    if gather_specs is not None:
+        # the forward ran embed_mlp_head_fwd(write_x=False): the stack input is gathered again from the tables
+        farr = _field_array(gather_specs)
+        rc = _timed("mlp_fused_bwd", meta, _lib.load().ctr_embed_mlp_head_bwd, farr, len(gather_specs), m, arr, len(layers),
+                    C.byref(hg), gx_first.data_ptr(), _ld(gx_first), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+        _lib.check(rc, "ctr_embed_mlp_head_bwd")  # a refusal is an error here: the input columns were never written
+        return grads
+    rc = _timed("mlp_fused_bwd", meta, _lib.load().ctr_mlp_head_bwd, x0.data_ptr(), _ld(x0), m, arr, len(layers),
+                C.byref(hg), gx_first.data_ptr(), _ld(gx_first), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
     if rc in _REFUSED:
         if _profiler is not None and _profiler.records and _profiler.records[-1][0] == "mlp_fused_bwd":
             _profiler.records.pop()

@@ -2,10 +2,10 @@
 mkdir -p gpurun_out/r02
 timeout -k 10 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_models.py -q -m gpu -x -k "gather_inside or neuralcf or NeuralCF or fused_head" 2>&1 | tail -8 &&
 for v in 1 0; do
-CTR_NCF_FUSED_GATHER=$v timeout -k 10 300 python bench.py --no-gather-leg --no-cpu-baseline --steps 100 --warmup 10 > gpurun_out/r02/bench_z.json 2> gpurun_out/r02/bench_z.err || tail -5 gpurun_out/r02/bench_z.err
+CTR_NCF_REGATHER=$v timeout -k 10 300 python bench.py --no-gather-leg --no-cpu-baseline --steps 100 --warmup 10 > gpurun_out/r02/bench_z.json 2> gpurun_out/r02/bench_z.err || tail -5 gpurun_out/r02/bench_z.err
 python - <<PY
 import json
 d = json.load(open("gpurun_out/r02/bench_z.json"))
-print("fused gather=$v:", round(d["value"]/1e6, 2), "M/s ms", round(d["ms_per_step"], 4), {k: v["avg_us"] for k, v in d["kernels"].items()})
+print("regather=$v:", round(d["value"]/1e6, 2), "M/s ms", round(d["ms_per_step"], 4), {k: v["avg_us"] for k, v in d["kernels"].items()})
 PY
 done

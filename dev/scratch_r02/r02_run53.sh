@@ -1,0 +1,8 @@
+#!/bin/bash
+mkdir -p gpurun_out/r02
+CTRHIP_LIB=dev/timing/libctrhip_stamps.so timeout -k 10 300 python bench.py --no-gather-leg --no-cpu-baseline --steps 50 --warmup 10 > gpurun_out/r02/bench_z.json 2> gpurun_out/r02/bench_z.err || tail -5 gpurun_out/r02/bench_z.err
+python - <<PY
+import json
+d = json.load(open("gpurun_out/r02/bench_z.json"))
+print("no-store experiment:", round(d["value"]/1e6, 2), "M/s ms", round(d["ms_per_step"], 4), {k: v["avg_us"] for k, v in d["kernels"].items()})
+PY

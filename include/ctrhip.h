@@ -382,10 +382,11 @@ int ctr_mlp_head_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer
  * for the pattern the library has a kernel for -- NeuralCF at BASELINE configs[1] (model/neuralcf.py:37-56:
  * fields = [ID_I64 64 -> column 0, ID_I64 64 -> column 64, PROD_I64 64 -> column 128] of one matrix, the pinned
  * 128-64-32-16-8 ReLU tower on columns 0..127, head->x = out + 128, p = 64).  The kernel reads the ids and table rows
- * itself and writes the gathered columns into `out` on the way (the backward passes read them there).  Any other
- * shape: CTR_ELIMIT, nothing enqueued -- issue the two calls. */
+ * itself.  The product columns (head->x) are always written; the tower's input columns 0..127 only with
+ * write_x != 0 -- with write_x == 0 they stay untouched and the backward must be ctr_embed_mlp_head_bwd, which
+ * gathers them again.  Any other shape: CTR_ELIMIT, nothing enqueued -- issue the two calls. */
 int ctr_embed_mlp_head_fwd(const ctr_field_t* fields, int nfields, int64_t batch, float* out, int64_t ldo,
-                           int32_t* err_flag /*nullable*/, const ctr_mlp_layer_t* layers, int nlayers,
+                           int32_t* err_flag /*nullable*/, int write_x, const ctr_mlp_layer_t* layers, int nlayers,
                            const ctr_mlp_head_t* head, void* stream);
 /* Backward of ctr_mlp_head_fwd in ONE launch with the stack's backward: per row gz = gprob * act'(prob);
  * the stack's gY is gz * w[p:] (never stored), gx_extra[row, 0:p] = gz * w[0:p] is written, and
@@ -406,6 +407,13 @@ typedef struct ctr_mlp_head_grad {
 int ctr_mlp_head_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
                      const ctr_mlp_head_grad_t* head, float* gx, int64_t ldgx, float* workspace,
                      int64_t workspace_floats, void* stream);
+/* ctr_mlp_head_bwd for a forward done by ctr_embed_mlp_head_fwd(..., write_x = 0, ...): the stack's input
+ * [table[idx] | table[idx]] of the first two fields is gathered again by the samples' ids (out-of-range ids read
+ * row 0, as in the forward) instead of being read from memory; hg->x is the product columns the forward wrote.
+ * Same outputs and workspace contract as ctr_mlp_head_bwd.  CTR_ELIMIT: not the pattern, nothing enqueued. */
+int ctr_embed_mlp_head_bwd(const ctr_field_t* fields, int nfields, int64_t batch, const ctr_mlp_layer_t* layers,
+                           int nlayers, const ctr_mlp_head_grad_t* hg, float* gx, int64_t ldgx, float* workspace,
+                           int64_t workspace_floats, void* stream);
 /* gy: gradient of the LAST layer's output; gx (nullable): gradient of x.  workspace is
  * required: (number of workgroups <= 256) * sum_i (n_i*k_i + n_i) floats. */
 int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,

@@ -478,6 +478,33 @@ def test_gather_inside_the_tower_forward_matches_the_two_launches(ops, m):
     torch.testing.assert_close(pf.cpu(), ps.cpu(), rtol=1e-5, atol=2e-6)
     assert not torch.isnan(bf).any()
 
+    # write_x=False: the tower input is never written, and ctr_embed_mlp_head_bwd gathers it again -- same gradients as
+    # the backward that reads the written columns
+    buf = torch.full((m, width), float("nan"), device=DEV)
+    head = ops.Head(buf[:, 128:192], w, c, 2)
+    acts = ops.embed_mlp_head_fwd(specs, m, buf, 128, layers, head, buf[:, 192:], None, write_x=False)
+    assert acts is not None and torch.isnan(buf[:, :128]).all()
+    assert torch.equal(buf[:, 128:192].cpu(), bf[:, 128:192].cpu()) and torch.equal(head.out.cpu(), pf.cpu())
+    gprob = torch.randn(m, 1, generator=g).to(DEV)
+    wz = w.new_zeros(w.shape)
+
+    def backward(acts_, head_, prob_, gather):
+        params = [l.weight for l in layers] + [l.bias for l in layers]
+        zeros = ops.zero_grads(params + [wz, c.new_empty(4)])
+        gwh, gch = zeros[id(wz)], list(zeros.values())[-1][:1]
+        gbuf = torch.full((m, 192), float("nan"), device=DEV)
+        grads = ops.mlp_head_bwd(acts_, layers, head_, prob_, gprob, gbuf[:, 128:192], gwh, gch, gbuf[:, :128], zeros,
+                                 gather_specs=specs if gather else None)
+        assert grads is not None
+        return [gbuf, gwh, gch] + [t for pair in grads for t in pair]
+
+    ref = backward(af, ops.Head(bf[:, 128:192], w, c, 2), pf, False)
+    got = backward(acts, head, head.out, True)
+    scale = m ** 0.5
+    for a, b in zip(got, ref):
+        assert not torch.isnan(a).any()
+        torch.testing.assert_close(a.cpu(), b.cpu(), rtol=1e-5, atol=2e-6 * scale)
+
 
 def test_tiled_tower_kernels_behind_the_switch():
     """CTR_MLP_16=0 selects the tiled fused-MLP kernels for the pinned NeuralCF tower (the A/B partner of the
