@@ -323,6 +323,7 @@ KERNEL_NAMES = {"embed_fwd_fast": ("embed_ids_fast_kernel",), "mlp_fused_bwd": (
 
 # what one event-bracketed C-ABI call covers when it is more than one kernel
 LABEL_NOTES = {
+    "embed_mlp_fused_fwd": "one ctr_embed_mlp_head_fwd call = ncf16_fwd_kernel<true>: ids -> table rows -> tower -> folded head",
     "mlp_fused_bwd": "one ctr_mlp_head_bwd call = ncf16_bwd_kernel (mlp_bwd_kernel for other stacks) + reduce_segments_kernel (+ the gap between them); "
                      "rocprofv3 lists them separately in profiles/*_kernel_stats.csv",
     "embed_bwd": "one ctr_embed_bwd call = sort_count/colscan/scatter + seg_reduce (small tables) and/or "
