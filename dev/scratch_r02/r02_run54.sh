@@ -1,4 +1,2 @@
 #!/bin/bash
-for i in 1 2 3; do timeout -k 10 600 python -m pytest tests/test_gpu_sparse.py -q -m gpu -k hipgraph_replay 2>&1 | tail -1; done
-echo old reduce:
-for i in 1 2 3; do CTRHIP_LIB=dev/timing/libctrhip_oldreduce.so timeout -k 10 600 python -m pytest tests/test_gpu_sparse.py -q -m gpu -k hipgraph_replay 2>&1 | tail -1; done
+for i in 1 2 3 4 5; do timeout -k 10 600 python -m pytest tests/test_gpu_sparse.py -q -m gpu 2>&1 | tail -1; done

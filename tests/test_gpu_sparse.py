@@ -70,11 +70,11 @@ def _train(module, batches, steps):
 def _compare(got, want):
     # Both sides scatter their embedding gradients with fp32 atomics, whose order is not fixed; Adam turns a last-bit
     # difference in a tiny gradient into a visible difference of the update (its step is lr * m / sqrt(v): the
-    # magnitude cancels).  The absolute slack is therefore tied to the learning rate -- 0.5 % of one step -- on top of
+    # magnitude cancels).  The absolute slack is therefore tied to the learning rate -- 1 % of one step -- on top of
     # the rounding terms; a wrong row, a missed update or a wrong hyper-parameter moves an element by a whole step.
     for k in want:
         scale = float(want[k].abs().max())
-        torch.testing.assert_close(got[k], want[k], rtol=2e-4, atol=1e-6 + 2e-5 * scale + 5e-3 * HYPER["lr"],
+        torch.testing.assert_close(got[k], want[k], rtol=2e-4, atol=1e-6 + 2e-5 * scale + 1e-2 * HYPER["lr"],
                                    msg=lambda s, k=k: f"{k}: {s}")
 
 
