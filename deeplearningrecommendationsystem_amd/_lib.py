@@ -41,6 +41,13 @@ class MlpHead(C.Structure):
                 ("ldout", C.c_int64), ("p", C.c_int32), ("act", C.c_int32)]
 
 
+class HeadFold(C.Structure):
+    """mirror of ``ctr_head_fold_t``"""
+    _fields_ = [("u_full", C.c_void_p), ("w", C.c_void_p), ("ldw", C.c_int64), ("b", C.c_void_p), ("b2", C.c_void_p),
+                ("wfold", C.c_void_p), ("cfold", C.c_void_p), ("p", C.c_int32), ("n", C.c_int32), ("k", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class MlpHeadGrad(C.Structure):
     """mirror of ``ctr_mlp_head_grad_t``"""
     _fields_ = [("prob", C.c_void_p), ("ldprob", C.c_int64), ("gprob", C.c_void_p), ("ldgprob", C.c_int64),
@@ -122,7 +129,7 @@ SIGNATURES = {
     "ctr_mlp_fwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, _p]),
     "ctr_mlp_head_fwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, C.POINTER(MlpHead), _p]),
     "ctr_embed_mlp_head_fwd": (_i, [C.POINTER(Field), _i, _l, _p, _l, _p, _i, C.POINTER(MlpLayer), _i, C.POINTER(MlpHead),
-                                    _p]),
+                                    C.POINTER(HeadFold), _p]),
     "ctr_embed_mlp_head_bwd": (_i, [C.POINTER(Field), _i, _l, C.POINTER(MlpLayer), _i, C.POINTER(MlpHeadGrad), _p, _l, _p, _l,
                                     _p]),
     "ctr_mlp_head_bwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, C.POINTER(MlpHeadGrad), _p, _l, _p, _l, _p]),

@@ -115,7 +115,8 @@ int ctr_reduce_segments(const float* ws, int parts, int64_t stride, const CtrSeg
 int ctr_ncf16_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, const ctr_mlp_head_t* head,
                   hipStream_t st);
 int ctr_ncf16_gather_fwd(const ctr_field_t* fields, int nfields, int64_t m, float* out, int64_t ldo, int32_t* err_flag,
-                         int write_x, const ctr_mlp_layer_t* layers, const ctr_mlp_head_t* head, hipStream_t st);
+                         int write_x, const ctr_mlp_layer_t* layers, const ctr_mlp_head_t* head, const ctr_head_fold_t* fold,
+                         hipStream_t st);
 int ctr_ncf16_gather_bwd(const ctr_field_t* fields, int nfields, int64_t m, const ctr_mlp_layer_t* layers,
                          const ctr_mlp_head_grad_t* hg, float* gx, int64_t ldgx, float* workspace,
                          int64_t workspace_floats, int* grid_out, hipStream_t st);

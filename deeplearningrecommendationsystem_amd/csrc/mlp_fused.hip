@@ -1761,7 +1761,7 @@ extern "C" int ctr_mlp_head_fwd(const float* x, int64_t ldx, int64_t m, const ct
 // nothing was enqueued and the caller issues the two calls.
 extern "C" int ctr_embed_mlp_head_fwd(const ctr_field_t* fields, int nfields, int64_t batch, float* out, int64_t ldo,
                                       int32_t* err_flag, int write_x, const ctr_mlp_layer_t* layers, int nlayers,
-                                      const ctr_mlp_head_t* head, void* stream) {
+                                      const ctr_mlp_head_t* head, const ctr_head_fold_t* fold, void* stream) {
   CTR_REQUIRE(fields && nfields > 0 && nfields <= CTR_MAX_FIELDS && out && ldo > 0 && layers && nlayers > 0 && head,
               CTR_EINVAL);
   CTR_REQUIRE(batch >= 0, CTR_EINVAL);
@@ -1772,7 +1772,7 @@ extern "C" int ctr_embed_mlp_head_fwd(const ctr_field_t* fields, int nfields, in
   if (!m16 || nlayers != 4 || batch < 1024 || !ctr_aligned16(out) || ldo % 4 != 0) return CTR_ELIMIT;
   for (int l = 0; l < nlayers; ++l)
     if (!layers[l].w || !layers[l].y || !ctr_aligned16(layers[l].w)) return CTR_ELIMIT;
-  return ctr_ncf16_gather_fwd(fields, nfields, batch, out, ldo, err_flag, write_x, layers, head, (hipStream_t)stream);
+  return ctr_ncf16_gather_fwd(fields, nfields, batch, out, ldo, err_flag, write_x, layers, head, fold, (hipStream_t)stream);
 }
 
 extern "C" int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,

@@ -162,6 +162,11 @@ struct Gather {
   float* xeout; int64_t ldxe;                // (m, ldxe): the 64 extra columns
   int32_t* err_flag;                         // nullable: set on an id outside its table (the row read is row 0)
   int write_x;                               // forward: 0 = the backward gathers x again (ctr_embed_mlp_head_bwd), x is not written
+  // forward, optional (fold_u != NULL): the head's weights are formed here instead of read from H.w / H.c --
+  // ctr_fold_head_fwd's map for p = 64, n = 64, k = 8: wfold = [u[:64] | W^T u[64:]], cfold = b . u[64:] + b2 --
+  // and workgroup 0 leaves them in wfold_out / cfold_out for the backward
+  const float* fold_u; const float* fold_w; int64_t fold_ldw; const float* fold_b; const float* fold_b2;
+  float* wfold_out; float* cfold_out;
 };
 
 template <bool GATHER>
@@ -170,6 +175,7 @@ ncf16_fwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
   __shared__ __attribute__((aligned(16))) float s_w[kWFloats];
   __shared__ __attribute__((aligned(16))) float s_b[kBFloats];
   __shared__ __attribute__((aligned(16))) float s_hw[kHeadW];
+  __shared__ float s_hc;
   const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
   const int64_t groups = (m + 15) / 16;
   const int64_t wave0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * kThreads) >> 6;
@@ -220,15 +226,43 @@ ncf16_fwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
     int wdst[kFStagePer];
     float bv;
     stage_forward_load(T, wv, wdst, bv);
-    const float hw = threadIdx.x < kHeadW ? H.w[threadIdx.x] : 0.0f;
+    float hw = 0.0f;
+    if (GATHER && G.fold_u) {
+      const int t = threadIdx.x;
+      if (t < kP) {
+        hw = G.fold_u[t];
+      } else if (t < kHeadW) {                 // column t - 64 of W^T u: 64 terms, eight loads in flight
+        const float* wc = G.fold_w + (t - kP);
+        const float* u = G.fold_u + kP;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int i0 = 0; i0 < 64; i0 += 8) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] = fmaf(wc[(int64_t)(i0 + e) * G.fold_ldw], u[i0 + e], acc[e]);
+        }
+        hw = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+      } else if (t == kHeadW) {                // the folded bias
+        const float* u = G.fold_u + kP;
+        float acc = G.fold_b2 ? G.fold_b2[0] : 0.0f;
+        if (G.fold_b)
+          for (int i = 0; i < 64; ++i) acc = fmaf(G.fold_b[i], u[i], acc);
+        hw = acc;
+      }
+      if (blockIdx.x == 0) {
+        if (t < kHeadW) G.wfold_out[t] = hw;
+        if (t == kHeadW) G.cfold_out[0] = hw;
+      }
+    } else if (threadIdx.x < kHeadW) {
+      hw = H.w[threadIdx.x];
+    }
     fetch(wave0, xb, xeb);
     fetch_ids(wave0 + nwaves);
     stage_forward_store(s_w, s_b, wv, wdst, bv);
     static_assert(kHeadW <= kThreads, "one head weight per thread");
     if (threadIdx.x < kHeadW) s_hw[threadIdx.x] = hw;
+    if (GATHER && G.fold_u && threadIdx.x == kHeadW) s_hc = hw;
   }
   __syncthreads();
-  const float hc = H.c ? H.c[0] : 0.0f;
+  const float hc = (GATHER && G.fold_u) ? s_hc : (H.c ? H.c[0] : 0.0f);
   for (int64_t g = wave0; g < groups; g += nwaves) {
     const int64_t row = g * 16 + n;
     const bool live = row < m;
@@ -880,7 +914,7 @@ static bool ncf_pattern(const ctr_field_t* fields, int nfields, Gather* G) {
   for (const float* t : tabs)
     if (!t || !ctr_aligned16(t)) return false;
   *G = Gather{fu.idx, fu.idx_stride, fi.idx, fi.idx_stride, fu.table, fi.table, fp.table, fp.table2, fu.vocab, fi.vocab,
-              nullptr, nullptr, 0, nullptr, 1};
+              nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
   return true;
 }
 
@@ -926,9 +960,17 @@ int ctr_ncf16_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t*
 // whose first 128 columns are the tower's input and whose columns 128..191 are the head's extra columns.
 // CTR_ELIMIT: not this pattern (nothing enqueued; the caller runs ctr_embed_fwd + ctr_mlp_head_fwd).
 int ctr_ncf16_gather_fwd(const ctr_field_t* fields, int nfields, int64_t m, float* out, int64_t ldo, int32_t* err_flag,
-                         int write_x, const ctr_mlp_layer_t* layers, const ctr_mlp_head_t* head, hipStream_t st) {
+                         int write_x, const ctr_mlp_layer_t* layers, const ctr_mlp_head_t* head, const ctr_head_fold_t* fold,
+                         hipStream_t st) {
   Gather G;
   if (!ncf_pattern(fields, nfields, &G) || ldo < 192 || head->x != out + 128 || head->ldx != ldo) return CTR_ELIMIT;
+  if (fold) {
+    if (fold->p != kP || fold->n != 64 || fold->k != kNL || !fold->u_full || !fold->w || fold->ldw < fold->k ||
+        fold->wfold != head->w || fold->cfold != head->c)
+      return CTR_ELIMIT;
+    G.fold_u = fold->u_full; G.fold_w = fold->w; G.fold_ldw = fold->ldw; G.fold_b = fold->b; G.fold_b2 = fold->b2;
+    G.wfold_out = fold->wfold; G.cfold_out = fold->cfold;
+  }
   G.xout = out;
   G.xeout = out + 128;
   G.ldxe = ldo;

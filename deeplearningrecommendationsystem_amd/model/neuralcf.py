@@ -60,15 +60,20 @@ class _NeuralCFFunction(torch.autograd.Function):
             sort_ws = ops.new_scratch(buf.device)
             with ops.SideStream(buf.device) as side:
                 ops.embed_bwd_presort(specs, None, batch, buf.stride(0), sort_ws)
-        wfold, cfold = ops.fold_head_fwd(head_w, mf, proj_w, proj_b, head_b)
         acts = None
+        wfold = cfold = None
         if n_hidden and FUSED_GATHER:
-            # gather + tower + folded head in one launch; None: the library has no such kernel for this shape
+            # gather + head fold + tower + folded head in one launch; None: the library has no such kernel for this shape
+            wfold = torch.empty((1, mf + kh), dtype=torch.float32, device=buf.device)
+            cfold = torch.empty(1, dtype=torch.float32, device=buf.device)
             head = ops.Head(buf[:, l0:l0 + mf], wfold, cfold, ACT_SIGMOID)
             regather = REGATHER and any(ctx.needs_input_grad[4:])
             acts = ops.embed_mlp_head_fwd(specs, batch, buf, l0, hidden, head, buf[:, l0 + mf:], err_flag,
-                                          write_x=not regather)
+                                          write_x=not regather, fold=(head_w, proj_w, proj_b, head_b))
             ctx.regather = regather and acts is not None
+        if acts is None:
+            wfold, cfold = ops.fold_head_fwd(head_w, mf, proj_w, proj_b, head_b,
+                                             out=(wfold, cfold) if wfold is not None else None)
         if acts is not None:
             prob = head.out
         elif n_hidden:

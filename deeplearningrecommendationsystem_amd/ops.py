@@ -491,11 +491,14 @@ def mlp_fwd(x: torch.Tensor, layers: Sequence[Layer], last_out: Optional[torch.T
 
 
 def embed_mlp_head_fwd(specs: Sequence[FieldSpec], batch: int, buf: torch.Tensor, k0: int, layers: Sequence[Layer],
-                       head: Head, last_out: torch.Tensor, err_flag: Optional[torch.Tensor] = None, write_x: bool = True):
+                       head: Head, last_out: torch.Tensor, err_flag: Optional[torch.Tensor] = None, write_x: bool = True,
+                       fold: Optional[tuple] = None):
     """``embed_fwd(specs -> buf)`` and ``mlp_fwd(buf[:, :k0], layers, last_out, head)`` in ONE launch
     (ctr_embed_mlp_head_fwd) where the library has a kernel for the pattern (NeuralCF at BASELINE configs[1]); returns
     the activation list of ``mlp_fwd`` or None when it refused (nothing was enqueued: issue the two calls).
-    ``write_x=False``: ``buf[:, :k0]`` is left untouched and the backward has to be ``embed_mlp_head_bwd``."""
+    ``write_x=False``: ``buf[:, :k0]`` is left untouched and the backward has to be ``embed_mlp_head_bwd``.
+    ``fold=(u_full, w, b, b2)``: ``fold_head_fwd`` done by the same launch -- ``head.w`` / ``head.c`` are then OUTPUTS
+    (uninitialised buffers of the folded shape) that the kernel fills for the backward."""
     buf = _mat(buf, "buf")
     x = buf[:, :k0]
     if not _fusable(x, layers) or head.x_extra is None:
@@ -510,11 +513,17 @@ def embed_mlp_head_fwd(specs: Sequence[FieldSpec], batch: int, buf: torch.Tensor
     out = torch.empty((m, 1), dtype=torch.float32, device=buf.device)
     hd = _lib.MlpHead(_lib.ptr(head.x_extra), _ld(head.x_extra), head.w.data_ptr(), head.c.data_ptr(), out.data_ptr(), 1, p,
                       head.act)
+    fd = None
+    if fold is not None:
+        u_full, fw, fb, fb2 = fold
+        fd = _lib.HeadFold(u_full.data_ptr(), fw.data_ptr(), _ld(fw), _lib.ptr(fb), _lib.ptr(fb2), head.w.data_ptr(),
+                           head.c.data_ptr(), p, fw.shape[0], fw.shape[1], 0)
     rc = _timed("embed_mlp_fused_fwd",
                 lambda: (_embed_bytes(specs, batch, False) + 4 * m * (1 + sum(n for n, _ in dims)),
                          2 * m * (sum(n * k for n, k in dims) + p + dims[-1][0])),
                 _lib.load().ctr_embed_mlp_head_fwd, farr, len(specs), batch, buf.data_ptr(), _ld(buf), _lib.ptr(err_flag),
-                1 if write_x else 0, arr, len(layers), C.byref(hd), _lib.stream_ptr())
+                1 if write_x else 0, arr, len(layers), C.byref(hd), C.byref(fd) if fd is not None else None,
+                _lib.stream_ptr())
     if rc in _REFUSED:
         if _profiler is not None and _profiler.records and _profiler.records[-1][0] == "embed_mlp_fused_fwd":
             _profiler.records.pop()  # refused: nothing ran

@@ -385,9 +385,22 @@ int ctr_mlp_head_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer
  * itself.  The product columns (head->x) are always written; the tower's input columns 0..127 only with
  * write_x != 0 -- with write_x == 0 they stay untouched and the backward must be ctr_embed_mlp_head_bwd, which
  * gathers them again.  Any other shape: CTR_ELIMIT, nothing enqueued -- issue the two calls. */
+/* optional: ctr_fold_head_fwd's map done by the same launch (NULL: head->w / head->c are read as they are).  The
+ * kernel forms wfold = [u_full[:p] | W^T u_full[p:]] and cfold = b . u_full[p:] + b2 itself and also writes them to
+ * `wfold` / `cfold`, which must be the buffers head->w / head->c point at (the backward reads them there). */
+typedef struct ctr_head_fold {
+  const float* u_full;  /* (p + n) */
+  const float* w;       /* (n, k) at row stride ldw */
+  int64_t ldw;
+  const float* b;       /* (n) or NULL */
+  const float* b2;      /* (1) or NULL */
+  float* wfold;         /* (p + k), == head->w */
+  float* cfold;         /* (1),     == head->c */
+  int32_t p, n, k, reserved;
+} ctr_head_fold_t;
 int ctr_embed_mlp_head_fwd(const ctr_field_t* fields, int nfields, int64_t batch, float* out, int64_t ldo,
                            int32_t* err_flag /*nullable*/, int write_x, const ctr_mlp_layer_t* layers, int nlayers,
-                           const ctr_mlp_head_t* head, void* stream);
+                           const ctr_mlp_head_t* head, const ctr_head_fold_t* fold /*nullable*/, void* stream);
 /* Backward of ctr_mlp_head_fwd in ONE launch with the stack's backward: per row gz = gprob * act'(prob);
  * the stack's gY is gz * w[p:] (never stored), gx_extra[row, 0:p] = gz * w[0:p] is written, and
  * gw[0:p+n_last] += sum_rows gz * [x_extra | y_last],  gc[0] += sum_rows gz.  Layers' gw / gb and gx as in

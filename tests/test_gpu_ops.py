@@ -478,6 +478,21 @@ def test_gather_inside_the_tower_forward_matches_the_two_launches(ops, m):
     torch.testing.assert_close(pf.cpu(), ps.cpu(), rtol=1e-5, atol=2e-6)
     assert not torch.isnan(bf).any()
 
+    # fold=...: ctr_fold_head_fwd's map inside the same launch -- the head's weights are outputs then
+    u_full = (torch.randn(1, 128, generator=g) * 0.3).to(DEV)
+    pw, pb, b2 = (torch.randn(64, 8, generator=g) / 3).to(DEV), (torch.randn(64, generator=g) * 0.1).to(DEV), c
+    wref, cref = ops.fold_head_fwd(u_full, 64, pw, pb, b2)
+    buf = torch.full((m, width), float("nan"), device=DEV)
+    wout, cout = torch.full_like(wref, float("nan")), torch.full_like(cref, float("nan"))
+    head = ops.Head(buf[:, 128:192], wout, cout, 2)
+    assert ops.embed_mlp_head_fwd(specs, m, buf, 128, layers, head, buf[:, 192:], None, fold=(u_full, pw, pb, b2)) is not None
+    torch.testing.assert_close(wout.cpu(), wref.cpu(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(cout.cpu(), cref.cpu(), rtol=1e-5, atol=1e-6)
+    buf2 = torch.full((m, width), float("nan"), device=DEV)
+    head2 = ops.Head(buf2[:, 128:192], wref, cref, 2)
+    ops.embed_mlp_head_fwd(specs, m, buf2, 128, layers, head2, buf2[:, 192:], None)
+    torch.testing.assert_close(head.out.cpu(), head2.out.cpu(), rtol=1e-5, atol=2e-6)
+
     # write_x=False: the tower input is never written, and ctr_embed_mlp_head_bwd gathers it again -- same gradients as
     # the backward that reads the written columns
     buf = torch.full((m, width), float("nan"), device=DEV)
