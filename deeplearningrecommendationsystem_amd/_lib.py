@@ -48,6 +48,13 @@ class HeadFold(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class HeadFoldGrad(C.Structure):
+    """mirror of ``ctr_head_fold_grad_t``"""
+    _fields_ = [("u_full", C.c_void_p), ("w", C.c_void_p), ("ldw", C.c_int64), ("b", C.c_void_p), ("gu_full", C.c_void_p),
+                ("gw", C.c_void_p), ("ldgw", C.c_int64), ("gb", C.c_void_p), ("gb2", C.c_void_p), ("p", C.c_int32),
+                ("n", C.c_int32), ("k", C.c_int32), ("reserved", C.c_int32)]
+
+
 class MlpHeadGrad(C.Structure):
     """mirror of ``ctr_mlp_head_grad_t``"""
     _fields_ = [("prob", C.c_void_p), ("ldprob", C.c_int64), ("gprob", C.c_void_p), ("ldgprob", C.c_int64),
@@ -130,8 +137,8 @@ SIGNATURES = {
     "ctr_mlp_head_fwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, C.POINTER(MlpHead), _p]),
     "ctr_embed_mlp_head_fwd": (_i, [C.POINTER(Field), _i, _l, _p, _l, _p, _i, C.POINTER(MlpLayer), _i, C.POINTER(MlpHead),
                                     C.POINTER(HeadFold), _p]),
-    "ctr_embed_mlp_head_bwd": (_i, [C.POINTER(Field), _i, _l, C.POINTER(MlpLayer), _i, C.POINTER(MlpHeadGrad), _p, _l, _p, _l,
-                                    _p]),
+    "ctr_embed_mlp_head_bwd": (_i, [C.POINTER(Field), _i, _l, C.POINTER(MlpLayer), _i, C.POINTER(MlpHeadGrad),
+                                    C.POINTER(HeadFoldGrad), _p, _l, _p, _l, _p]),
     "ctr_mlp_head_bwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, C.POINTER(MlpHeadGrad), _p, _l, _p, _l, _p]),
     "ctr_mlp_bwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, _p, _l, _p, _l, _p, _l, _p]),
     "ctr_negative_sample": (_i, [_p, _l, _l, _l, _i, C.c_uint64, _p, _p, _p, _p]),

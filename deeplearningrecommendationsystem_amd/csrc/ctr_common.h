@@ -109,6 +109,15 @@ struct CtrSegments {
   CtrSegment s[CTR_MAX_SEGMENTS];
 };
 int ctr_reduce_segments(const float* ws, int parts, int64_t stride, const CtrSegments& segs, hipStream_t st);
+// the same plus NeuralCF's head sums at float `head_off` of a partial (72 weights + 1 bias) and ctr_fold_head_bwd's chain
+// rule from their totals (p = 64, n = 64, k = 8), in one launch
+struct CtrHeadFoldGrad {
+  const float* u_full; const float* w; int64_t ldw; const float* b;
+  float* gwfold; float* gcfold;          // receive the sums (+=)
+  float* gu_full; float* gw; int64_t ldgw; float* gb; float* gb2;   // each nullable, accumulated (+=)
+};
+int ctr_reduce_segments_fold(const float* ws, int parts, int64_t stride, const CtrSegments& segs, int64_t head_off,
+                             const CtrHeadFoldGrad& fold, hipStream_t st);
 
 // mlp_mfma16.hip: the pinned NeuralCF tower + 64-column head with activations in matrix-core operand layout
 // (CTR_ELIMIT: shape / alignment not taken, nothing enqueued)

@@ -1832,8 +1832,9 @@ extern "C" int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp
 // fields != NULL: the stack's input is gathered from the fields' tables (ctr_embed_mlp_head_bwd); x then only stands for
 // "the matrix the forward wrote the other columns into" and is not read
 static int mlp_head_bwd_impl(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t m,
-                             const ctr_mlp_layer_t* layers, int nlayers, const ctr_mlp_head_grad_t* hg, float* gx,
-                             int64_t ldgx, float* workspace, int64_t workspace_floats, void* stream) {
+                             const ctr_mlp_layer_t* layers, int nlayers, const ctr_mlp_head_grad_t* hg,
+                             const ctr_head_fold_grad_t* fold, float* gx, int64_t ldgx, float* workspace,
+                             int64_t workspace_floats, void* stream) {
   CTR_REQUIRE(m >= 0 && hg, CTR_EINVAL);
   if (m == 0) return CTR_OK;
   CTR_REQUIRE(x && workspace, CTR_EINVAL);
@@ -1921,6 +1922,14 @@ static int mlp_head_bwd_impl(const ctr_field_t* fields, int nfields, const float
     segs.s[segs.n++] = CtrSegment{off + wn, layers[i].n, layers[i].gb};
     off += wn + layers[i].n;
   }
+  if (fold) {
+    if (fold->p != kHeadBwdP || fold->n != 64 || fold->k != kHeadBwdN || !fold->u_full || !fold->w || fold->ldw < fold->k ||
+        (fold->gw && fold->ldgw < fold->k))
+      return CTR_EINVAL;   // (checked before anything was enqueued would be nicer; these are caller bugs, not shapes)
+    const CtrHeadFoldGrad F{fold->u_full, fold->w, fold->ldw, fold->b, hg->gw, hg->gc, fold->gu_full, fold->gw, fold->ldgw,
+                            fold->gb, fold->gb2};
+    return ctr_reduce_segments_fold(workspace, (int)grid, slab, segs, off, F, st);
+  }
   segs.s[segs.n++] = CtrSegment{off, kHeadBwdP + kHeadBwdN, hg->gw};
   segs.s[segs.n++] = CtrSegment{off + kHeadBwdP + kHeadBwdN, 1, hg->gc};
   return ctr_reduce_segments(workspace, (int)grid, slab, segs, st);
@@ -1929,15 +1938,19 @@ static int mlp_head_bwd_impl(const ctr_field_t* fields, int nfields, const float
 extern "C" int ctr_mlp_head_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,
                                 const ctr_mlp_head_grad_t* hg, float* gx, int64_t ldgx, float* workspace,
                                 int64_t workspace_floats, void* stream) {
-  return mlp_head_bwd_impl(nullptr, 0, x, ldx, m, layers, nlayers, hg, gx, ldgx, workspace, workspace_floats, stream);
+  return mlp_head_bwd_impl(nullptr, 0, x, ldx, m, layers, nlayers, hg, nullptr, gx, ldgx, workspace, workspace_floats, stream);
 }
 
 // Backward of ctr_embed_mlp_head_fwd(..., write_x = 0, ...): as ctr_mlp_head_bwd, with the stack's input gathered again
 // from the fields' tables by the samples' ids instead of read from memory.  CTR_ELIMIT: not the pattern.
 extern "C" int ctr_embed_mlp_head_bwd(const ctr_field_t* fields, int nfields, int64_t batch, const ctr_mlp_layer_t* layers,
-                                      int nlayers, const ctr_mlp_head_grad_t* hg, float* gx, int64_t ldgx,
-                                      float* workspace, int64_t workspace_floats, void* stream) {
+                                      int nlayers, const ctr_mlp_head_grad_t* hg, const ctr_head_fold_grad_t* fold,
+                                      float* gx, int64_t ldgx, float* workspace, int64_t workspace_floats, void* stream) {
   CTR_REQUIRE(fields && nfields > 0 && nfields <= CTR_MAX_FIELDS && hg, CTR_EINVAL);
-  return mlp_head_bwd_impl(fields, nfields, hg->x, hg->ldx, batch, layers, nlayers, hg, gx, ldgx, workspace,
+  if (fold)
+    CTR_REQUIRE(fold->p == kHeadBwdP && fold->n == 64 && fold->k == kHeadBwdN && fold->u_full && fold->w &&
+                    fold->ldw >= fold->k && (!fold->gw || fold->ldgw >= fold->k),
+                CTR_EINVAL);
+  return mlp_head_bwd_impl(fields, nfields, hg->x, hg->ldx, batch, layers, nlayers, hg, fold, gx, ldgx, workspace,
                            workspace_floats, stream);
 }

@@ -115,6 +115,9 @@ class _NeuralCFFunction(torch.autograd.Function):
         zeros = ops.zero_grads(list(tables) + list(dense) + [wfold, cfold_like.new_empty(4)])
         gwfold, gcfold = zeros[id(wfold)], list(zeros.values())[-1][:1]
         gbuf = torch.empty_like(buf)
+        g_proj_w, g_proj_b = zeros[id(proj_w)], zeros[id(proj_b)]
+        g_head_w, g_head_b = zeros[id(head_w)], zeros[id(head_b)]
+        folded = False
         if n_hidden:
             acts = [buf[:, :l0]] + mids + [buf[:, l0 + mf:]]
             # head backward + tower backward in one launch where the library has it (the BASELINE tower) ...
@@ -122,7 +125,11 @@ class _NeuralCFFunction(torch.autograd.Function):
             layer_grads = ops.mlp_head_bwd(acts, hidden, head, prob, gprob.contiguous(), gbuf[:, l0:l0 + mf], gwfold,
                                            gcfold, gbuf[:, :l0], zeros,
                                            gather_specs=_specs(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i)
+                                           if ctx.regather else None,
+                                           # ... and fold_head_bwd in that call's reduction launch
+                                           fold_grad=(head_w, proj_w, proj_b, g_head_w, g_proj_w, g_proj_b, g_head_b)
                                            if ctx.regather else None)
+            folded = ctx.regather
             if layer_grads is None:
                 # ... else the head as a single-unit layer on [gmf | h], then the tower
                 ops.linear_bwd(buf[:, l0:], wfold, prob, gprob.contiguous(), ACT_SIGMOID, gbuf[:, l0:], gwfold, gcfold)
@@ -133,9 +140,8 @@ class _NeuralCFFunction(torch.autograd.Function):
             ops.linear_bwd(buf, wf, prob, gprob.contiguous(), ACT_SIGMOID, gbuf, gwf, gcfold)
             gwfold.copy_(torch.cat([gwf[:, l0:], gwf[:, :l0]], dim=1))
             layer_grads = []
-        g_proj_w, g_proj_b = zeros[id(proj_w)], zeros[id(proj_b)]
-        g_head_w, g_head_b = zeros[id(head_w)], zeros[id(head_b)]
-        ops.fold_head_bwd(head_w, mf, proj_w, proj_b, gwfold, gcfold, g_head_w, g_proj_w, g_proj_b, g_head_b)
+        if not folded:
+            ops.fold_head_bwd(head_w, mf, proj_w, proj_b, gwfold, gcfold, g_head_w, g_proj_w, g_proj_b, g_head_b)
         tgrads = zeros
         if ctx.sort_side is not None:
             ctx.sort_side.join()  # the sort the forward started

@@ -550,7 +550,8 @@ def _head_unfused(head: Optional[Head], y_last: torch.Tensor) -> None:
 
 def mlp_head_bwd(acts: Sequence[torch.Tensor], layers: Sequence[Layer], head: Head, prob: torch.Tensor,
                  gprob: torch.Tensor, g_extra: torch.Tensor, gw_head: torch.Tensor, gc_head: torch.Tensor,
-                 gx_first: torch.Tensor, zeros: dict, gather_specs: Optional[Sequence[FieldSpec]] = None):
+                 gx_first: torch.Tensor, zeros: dict, gather_specs: Optional[Sequence[FieldSpec]] = None,
+                 fold_grad: Optional[tuple] = None):
     """backward of ``mlp_fwd(..., head=head)`` in one launch (ctr_mlp_head_bwd): the head's gz, the stack's
     backward, ``g_extra = gz * w[:p]`` and the head's weight / bias sums.  Returns the per-layer
     ``[(gw, gb)]`` or None when the library has no fused path for this stack (nothing was enqueued)."""
@@ -574,8 +575,16 @@ def mlp_head_bwd(acts: Sequence[torch.Tensor], layers: Sequence[Layer], head: He
     if gather_specs is not None:
         # the forward ran embed_mlp_head_fwd(write_x=False): the stack input is gathered again from the tables
         farr = _field_array(gather_specs)
+        fg = None
+        if fold_grad is not None:
+            # fold_head_bwd in the reduction launch of the same call: (u_full, w, b, gu_full, gw, gb, gb2)
+            fu, fw, fb, gu, gw_, gb_, gb2_ = fold_grad
+            fg = _lib.HeadFoldGrad(fu.data_ptr(), fw.data_ptr(), _ld(fw), _lib.ptr(fb), _lib.ptr(gu), _lib.ptr(gw_),
+                                   _ld(gw_) if gw_ is not None else 0, _lib.ptr(gb_), _lib.ptr(gb2_), p, fw.shape[0],
+                                   fw.shape[1], 0)
         rc = _timed("mlp_fused_bwd", meta, _lib.load().ctr_embed_mlp_head_bwd, farr, len(gather_specs), m, arr, len(layers),
-                    C.byref(hg), gx_first.data_ptr(), _ld(gx_first), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+                    C.byref(hg), C.byref(fg) if fg is not None else None, gx_first.data_ptr(), _ld(gx_first), ws.data_ptr(),
+                    ws.numel(), _lib.stream_ptr())
         _lib.check(rc, "ctr_embed_mlp_head_bwd")  # a refusal is an error here: the input columns were never written
         return grads
     rc = _timed("mlp_fused_bwd", meta, _lib.load().ctr_mlp_head_bwd, x0.data_ptr(), _ld(x0), m, arr, len(layers),

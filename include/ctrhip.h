@@ -424,9 +424,23 @@ int ctr_mlp_head_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer
  * [table[idx] | table[idx]] of the first two fields is gathered again by the samples' ids (out-of-range ids read
  * row 0, as in the forward) instead of being read from memory; hg->x is the product columns the forward wrote.
  * Same outputs and workspace contract as ctr_mlp_head_bwd.  CTR_ELIMIT: not the pattern, nothing enqueued. */
+/* optional (NULL: hg->gw / hg->gc only): ctr_fold_head_bwd done by the reduction launch of the same call, from the
+ * totals hg->gw (p + k) / hg->gc hold afterwards -- same arguments and (+=) semantics as ctr_fold_head_bwd. */
+typedef struct ctr_head_fold_grad {
+  const float* u_full;  /* (p + n) */
+  const float* w;       /* (n, k) at row stride ldw */
+  int64_t ldw;
+  const float* b;       /* (n) or NULL */
+  float* gu_full;       /* (p + n) or NULL */
+  float* gw;            /* (n, k) at row stride ldgw, or NULL */
+  int64_t ldgw;
+  float* gb;            /* (n) or NULL */
+  float* gb2;           /* (1) or NULL */
+  int32_t p, n, k, reserved;
+} ctr_head_fold_grad_t;
 int ctr_embed_mlp_head_bwd(const ctr_field_t* fields, int nfields, int64_t batch, const ctr_mlp_layer_t* layers,
-                           int nlayers, const ctr_mlp_head_grad_t* hg, float* gx, int64_t ldgx, float* workspace,
-                           int64_t workspace_floats, void* stream);
+                           int nlayers, const ctr_mlp_head_grad_t* hg, const ctr_head_fold_grad_t* fold /*nullable*/,
+                           float* gx, int64_t ldgx, float* workspace, int64_t workspace_floats, void* stream);
 /* gy: gradient of the LAST layer's output; gx (nullable): gradient of x.  workspace is
  * required: (number of workgroups <= 256) * sum_i (n_i*k_i + n_i) floats. */
 int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,

@@ -55,6 +55,8 @@ def test_field_struct_matches_header_size(lib):
     assert ctypes.sizeof(lib.MlpHeadGrad) == 96
     # pointer + pointer + int64 + 4 pointers + 4 int32 = 72 bytes, as ctr_head_fold_t
     assert ctypes.sizeof(lib.HeadFold) == 72
+    # 9 pointers / int64 + 4 int32 = 88 bytes, as ctr_head_fold_grad_t
+    assert ctypes.sizeof(lib.HeadFoldGrad) == 88
 
 
 def test_strerror(lib):
@@ -110,6 +112,8 @@ def _parse_header_prototypes():
                     kinds.append("headgrad*")
                 elif "ctr_mlp_head_t" in a:
                     kinds.append("head*")
+                elif "ctr_head_fold_grad_t" in a:
+                    kinds.append("foldgrad*")
                 elif "ctr_head_fold_t" in a:
                     kinds.append("fold*")
                 elif "ctr_adam_tensor_t" in a:
@@ -159,6 +163,8 @@ def test_ctypes_signatures_match_header_prototypes(lib):
                 got.append("headgrad*")
             elif a is ctypes.POINTER(lib.HeadFold):
                 got.append("fold*")
+            elif a is ctypes.POINTER(lib.HeadFoldGrad):
+                got.append("foldgrad*")
             elif a is ctypes.POINTER(lib.AdamTensor):
                 got.append("adam*")
             elif a is ctypes.POINTER(lib.RowsMark):
