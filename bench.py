@@ -324,7 +324,8 @@ KERNEL_NAMES = {"embed_fwd_fast": ("embed_ids_fast_kernel",), "mlp_fused_bwd": (
 # what one event-bracketed C-ABI call covers when it is more than one kernel
 LABEL_NOTES = {
     "embed_mlp_fused_fwd": "one ctr_embed_mlp_head_fwd call = ncf16_fwd_kernel<true>: ids -> table rows -> tower -> folded head",
-    "mlp_fused_bwd": "one ctr_mlp_head_bwd call = ncf16_bwd_kernel (mlp_bwd_kernel for other stacks) + reduce_segments_kernel (+ the gap between them); "
+    "mlp_fused_bwd": "one ctr_embed_mlp_head_bwd / ctr_mlp_head_bwd call = ncf16_bwd_kernel (mlp_bwd_kernel for other stacks) + "
+                     "reduce_segments(_fold)_kernel (with the head fold's backward) + the gap between them; "
                      "rocprofv3 lists them separately in profiles/*_kernel_stats.csv",
     "embed_bwd": "one ctr_embed_bwd call = sort_count/colscan/scatter + seg_reduce (small tables) and/or "
                  "bag_bwd + reduce_segments and/or embed_bwd_kernel",
@@ -349,6 +350,36 @@ def pmc_traffic(workload, label):
             if k.startswith(name):
                 return {"hbm_bytes_raw": v["hbm_bytes_raw"], "hbm_bytes_fetch_x2": v["hbm_bytes_fetchx2"],
                         "kernel": k, "source": os.path.relpath(files[-1], ROOT)}
+    return None
+
+
+def rocprof_kernel(workload, label, flops, nbytes):
+    """the dominant KERNEL of a multi-kernel call alone, from the newest committed rocprofv3 summary of this command
+    (profiles/*_<workload>_kernel_stats.csv): the event pair above brackets the whole C call (kernel + its reduction
+    launch), this is the cross-check the contract asks for, per kernel.  None when no summary is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_kernel_stats.csv")))
+    names = KERNEL_NAMES.get(label)
+    if not files or names is None:
+        return None
+    try:
+        rows = list(csv.DictReader(open(files[-1])))
+    except OSError:
+        return None
+    for name in names:
+        for r in rows:
+            short = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+            if short.startswith(name):
+                us = float(r["AverageNs"]) / 1e3
+                out = {"kernel": short.split("(")[0], "avg_us": round(us, 2), "calls": int(r["Calls"]),
+                       "source": os.path.relpath(files[-1], ROOT)}
+                if flops:
+                    out["tflops"] = round(flops / us / 1e6, 2)
+                    out["frac_of_f32_mfma_peak"] = round(flops / us / 1e6 / F32_MFMA_PEAK_TF, 4)
+                if nbytes:
+                    out["algorithmic_gbs"] = round(nbytes / us / 1e3, 1)
+                return out
     return None
 
 
@@ -514,7 +545,9 @@ def main():
                        else "single"},
             "loss": float(loss.item()), "launch": "eager" if args.no_graph else "hipGraph replay",
             "roofline": dict(entries[dominant], traffic=pmc_traffic(args.workload, dominant),
-                             note=LABEL_NOTES.get(dominant)),
+                             note=LABEL_NOTES.get(dominant),
+                             kernel_alone_rocprofv3=rocprof_kernel(args.workload, dominant, kernels[dominant]["flops"],
+                                                                   kernels[dominant]["bytes"])),
             # metric (ii) is defined on the HBM-resident cfg3b shape (gather_stage_leg); the step's own embedding
             # kernel is reported under its own key -- for NeuralCF / ml-100k vocabularies its tables are cache-resident
             "gather_roofline": gather_leg,
