@@ -93,11 +93,15 @@ reduce_segments_fold_kernel(const float* __restrict__ ws, int parts, int64_t str
 #pragma unroll
   for (int u = 0; u < 8; ++u) acc[u] = 0.0f;
   if (o < kSums) {
+    // this workgroup is alone with 73 x parts loads: sixteen in flight per thread (four rounds for 256 partials)
     const float* src = ws + hoff + o;
     int p = pl;
-    for (; p + 7 * 4 < parts; p += 8 * 4) {
+    for (; p + 15 * 4 < parts; p += 16 * 4) {
+      float v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc[u] += src[(int64_t)(p + 4 * u) * stride];
+      for (int u = 0; u < 16; ++u) v[u] = src[(int64_t)(p + 4 * u) * stride];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[u & 7] += v[u];
     }
     for (; p < parts; p += 4) acc[0] += src[(int64_t)p * stride];
   }
