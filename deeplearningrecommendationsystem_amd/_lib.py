@@ -138,7 +138,7 @@ SIGNATURES = {
     "ctr_embed_mlp_head_fwd": (_i, [C.POINTER(Field), _i, _l, _p, _l, _p, _i, C.POINTER(MlpLayer), _i, C.POINTER(MlpHead),
                                     C.POINTER(HeadFold), _p]),
     "ctr_embed_mlp_head_bwd": (_i, [C.POINTER(Field), _i, _l, C.POINTER(MlpLayer), _i, C.POINTER(MlpHeadGrad),
-                                    C.POINTER(HeadFoldGrad), _p, _l, _p, _l, _p]),
+                                    C.POINTER(HeadFoldGrad), _p, _l, _p, _l, _p, _l, _p]),
     "ctr_mlp_head_bwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, C.POINTER(MlpHeadGrad), _p, _l, _p, _l, _p]),
     "ctr_mlp_bwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, _p, _l, _p, _l, _p, _l, _p]),
     "ctr_negative_sample": (_i, [_p, _l, _l, _l, _i, C.c_uint64, _p, _p, _p, _p]),

@@ -128,7 +128,7 @@ int ctr_ncf16_gather_fwd(const ctr_field_t* fields, int nfields, int64_t m, floa
                          hipStream_t st);
 int ctr_ncf16_gather_bwd(const ctr_field_t* fields, int nfields, int64_t m, const ctr_mlp_layer_t* layers,
                          const ctr_mlp_head_grad_t* hg, float* gx, int64_t ldgx, float* workspace,
-                         int64_t workspace_floats, int* grid_out, hipStream_t st);
+                         int64_t workspace_floats, int* grid_out, float* zero_buf, int64_t zero_floats, hipStream_t st);
 int ctr_ncf16_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, const ctr_mlp_head_grad_t* hg,
                   float* gx, int64_t ldgx, float* workspace, int64_t workspace_floats, int* grid_out, hipStream_t st);
 int ctr_ncf16_slab_floats();

@@ -1834,7 +1834,7 @@ extern "C" int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp
 static int mlp_head_bwd_impl(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t m,
                              const ctr_mlp_layer_t* layers, int nlayers, const ctr_mlp_head_grad_t* hg,
                              const ctr_head_fold_grad_t* fold, float* gx, int64_t ldgx, float* workspace,
-                             int64_t workspace_floats, void* stream) {
+                             int64_t workspace_floats, void* stream, float* zero_buf = nullptr, int64_t zero_floats = 0) {
   CTR_REQUIRE(m >= 0 && hg, CTR_EINVAL);
   if (m == 0) return CTR_OK;
   CTR_REQUIRE(x && workspace, CTR_EINVAL);
@@ -1864,7 +1864,8 @@ static int mlp_head_bwd_impl(const ctr_field_t* fields, int nfields, const float
   bool done16 = false;
   if (m16 && gx && slab == ctr_ncf16_slab_floats()) {
     int g16 = 0;
-    rc = fields ? ctr_ncf16_gather_bwd(fields, nfields, m, layers, hg, gx, ldgx, workspace, workspace_floats, &g16, st)
+    rc = fields ? ctr_ncf16_gather_bwd(fields, nfields, m, layers, hg, gx, ldgx, workspace, workspace_floats, &g16, zero_buf,
+                                       zero_floats, st)
                 : ctr_ncf16_bwd(x, ldx, m, layers, hg, gx, ldgx, workspace, workspace_floats, &g16, st);
     if (rc == CTR_OK) {
       grid = g16;
@@ -1945,12 +1946,14 @@ extern "C" int ctr_mlp_head_bwd(const float* x, int64_t ldx, int64_t m, const ct
 // from the fields' tables by the samples' ids instead of read from memory.  CTR_ELIMIT: not the pattern.
 extern "C" int ctr_embed_mlp_head_bwd(const ctr_field_t* fields, int nfields, int64_t batch, const ctr_mlp_layer_t* layers,
                                       int nlayers, const ctr_mlp_head_grad_t* hg, const ctr_head_fold_grad_t* fold,
-                                      float* gx, int64_t ldgx, float* workspace, int64_t workspace_floats, void* stream) {
+                                      float* gx, int64_t ldgx, float* workspace, int64_t workspace_floats,
+                                      float* zero_buf, int64_t zero_floats, void* stream) {
   CTR_REQUIRE(fields && nfields > 0 && nfields <= CTR_MAX_FIELDS && hg, CTR_EINVAL);
+  CTR_REQUIRE(!zero_buf || zero_floats >= 0, CTR_EINVAL);
   if (fold)
     CTR_REQUIRE(fold->p == kHeadBwdP && fold->n == 64 && fold->k == kHeadBwdN && fold->u_full && fold->w &&
                     fold->ldw >= fold->k && (!fold->gw || fold->ldgw >= fold->k),
                 CTR_EINVAL);
   return mlp_head_bwd_impl(fields, nfields, hg->x, hg->ldx, batch, layers, nlayers, hg, fold, gx, ldgx, workspace,
-                           workspace_floats, stream);
+                           workspace_floats, stream, zero_buf, zero_floats);
 }

@@ -167,6 +167,9 @@ struct Gather {
   // and workgroup 0 leaves them in wfold_out / cfold_out for the backward
   const float* fold_u; const float* fold_w; int64_t fold_ldw; const float* fold_b; const float* fold_b2;
   float* wfold_out; float* cfold_out;
+  // backward, optional: a buffer to clear before anything of this call accumulates into it (the step's gradient
+  // buffers: the zero fill was a launch of its own)
+  float* zero_buf; int64_t zero_floats;      // 16-byte aligned, a multiple of 4 floats
 };
 
 template <bool GATHER>
@@ -593,6 +596,11 @@ ncf16_bwd_kernel(const Tower T, const float* __restrict__ x, int64_t ldx, int64_
       }
   };
   STAMP(0);
+  if (GATHER && G.zero_buf) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t i = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * 4; i < G.zero_floats; i += (int64_t)gridDim.x * kThreads * 4)
+      stg4(G.zero_buf + i, z);
+  }
   // ---- what a lane sums over every group it walks (zeroed first: 350 moves that then pass under the first loads)
   f32x4 dw0[4][8], dw1[2][4], dw2[2], dw3;                   // dW blocks: register r = row 4q + r, column lo
   f32x4 sb0[4], sb1[2], sb2, sb3;                            // bias sums of this lane's sample: units 4q + r
@@ -914,7 +922,7 @@ static bool ncf_pattern(const ctr_field_t* fields, int nfields, Gather* G) {
   for (const float* t : tabs)
     if (!t || !ctr_aligned16(t)) return false;
   *G = Gather{fu.idx, fu.idx_stride, fi.idx, fi.idx_stride, fu.table, fi.table, fp.table, fp.table2, fu.vocab, fi.vocab,
-              nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+              nullptr, nullptr, 0, nullptr, 1, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
   return true;
 }
 
@@ -922,9 +930,12 @@ static bool ncf_pattern(const ctr_field_t* fields, int nfields, Gather* G) {
 // the row stride the forward used for the other columns and are not read
 int ctr_ncf16_gather_bwd(const ctr_field_t* fields, int nfields, int64_t m, const ctr_mlp_layer_t* layers,
                          const ctr_mlp_head_grad_t* hg, float* gx, int64_t ldgx, float* workspace,
-                         int64_t workspace_floats, int* grid_out, hipStream_t st) {
+                         int64_t workspace_floats, int* grid_out, float* zero_buf, int64_t zero_floats, hipStream_t st) {
   Gather G;
   if (!ncf_pattern(fields, nfields, &G)) return CTR_ELIMIT;
+  if (zero_buf && (!ctr_aligned16(zero_buf) || zero_floats % 4 != 0)) return CTR_ELIMIT;
+  G.zero_buf = zero_buf;
+  G.zero_floats = zero_buf ? zero_floats : 0;
   return ncf16_bwd_launch(hg->x, hg->ldx, m, layers, hg, gx, ldgx, workspace, workspace_floats, grid_out, &G, st);
 }
 

@@ -112,7 +112,10 @@ class _NeuralCFFunction(torch.autograd.Function):
 
         tables = (gmf_u, gmf_i, mlp_u, mlp_i)
         cfold_like = head_b  # (1,)
-        zeros = ops.zero_grads(list(tables) + list(dense) + [wfold, cfold_like.new_empty(4)])
+        # (with the gathering backward the flat gradient buffer is cleared by that call's first launch, not by a fill)
+        zeros = ops.zero_grads(list(tables) + list(dense) + [wfold, cfold_like.new_empty(4)],
+                               lazy=bool(ctx.regather and n_hidden))
+        flat = zeros.pop("flat", None)
         gwfold, gcfold = zeros[id(wfold)], list(zeros.values())[-1][:1]
         gbuf = torch.empty_like(buf)
         g_proj_w, g_proj_b = zeros[id(proj_w)], zeros[id(proj_b)]
@@ -128,7 +131,7 @@ class _NeuralCFFunction(torch.autograd.Function):
                                            if ctx.regather else None,
                                            # ... and fold_head_bwd in that call's reduction launch
                                            fold_grad=(head_w, proj_w, proj_b, g_head_w, g_proj_w, g_proj_b, g_head_b)
-                                           if ctx.regather else None)
+                                           if ctx.regather else None, zero=flat)
             folded = ctx.regather
             if layer_grads is None:
                 # ... else the head as a single-unit layer on [gmf | h], then the tower

@@ -356,10 +356,12 @@ class Layer:
     act: int
 
 
-def zero_grads(tensors: Sequence[torch.Tensor]) -> dict:
+def zero_grads(tensors: Sequence[torch.Tensor], lazy: bool = False) -> dict:
     """{id(t): zero tensor shaped like t} for every parameter of a backward pass, carved
     out of ONE flat buffer so a step issues a single memset instead of one per
-    parameter (each piece starts 16-byte aligned)."""
+    parameter (each piece starts 16-byte aligned).  ``lazy=True``: the flat buffer is NOT filled; it is returned
+    under the key ``"flat"`` and whoever launches first has to clear it (``mlp_head_bwd(zero=...)``) or call
+    ``.zero_()`` on it."""
     out = {}
     dense = []
     for t in tensors:
@@ -375,7 +377,9 @@ def zero_grads(tensors: Sequence[torch.Tensor]) -> dict:
     if not dense:
         return out
     sizes = [(t.numel() + 3) // 4 * 4 for t in dense]
-    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dense[0].device)
+    flat = (torch.empty if lazy else torch.zeros)(sum(sizes), dtype=torch.float32, device=dense[0].device)
+    if lazy:
+        out["flat"] = flat
     off = 0
     for t, n in zip(dense, sizes):
         out[id(t)] = flat[off:off + t.numel()].view(t.shape)
@@ -551,7 +555,7 @@ def _head_unfused(head: Optional[Head], y_last: torch.Tensor) -> None:
 def mlp_head_bwd(acts: Sequence[torch.Tensor], layers: Sequence[Layer], head: Head, prob: torch.Tensor,
                  gprob: torch.Tensor, g_extra: torch.Tensor, gw_head: torch.Tensor, gc_head: torch.Tensor,
                  gx_first: torch.Tensor, zeros: dict, gather_specs: Optional[Sequence[FieldSpec]] = None,
-                 fold_grad: Optional[tuple] = None):
+                 fold_grad: Optional[tuple] = None, zero: Optional[torch.Tensor] = None):
     """backward of ``mlp_fwd(..., head=head)`` in one launch (ctr_mlp_head_bwd): the head's gz, the stack's
     backward, ``g_extra = gz * w[:p]`` and the head's weight / bias sums.  Returns the per-layer
     ``[(gw, gb)]`` or None when the library has no fused path for this stack (nothing was enqueued)."""
@@ -584,7 +588,7 @@ def mlp_head_bwd(acts: Sequence[torch.Tensor], layers: Sequence[Layer], head: He
                                    fw.shape[1], 0)
         rc = _timed("mlp_fused_bwd", meta, _lib.load().ctr_embed_mlp_head_bwd, farr, len(gather_specs), m, arr, len(layers),
                     C.byref(hg), C.byref(fg) if fg is not None else None, gx_first.data_ptr(), _ld(gx_first), ws.data_ptr(),
-                    ws.numel(), _lib.stream_ptr())
+                    ws.numel(), _lib.ptr(zero), zero.numel() if zero is not None else 0, _lib.stream_ptr())
         _lib.check(rc, "ctr_embed_mlp_head_bwd")  # a refusal is an error here: the input columns were never written
         return grads
     rc = _timed("mlp_fused_bwd", meta, _lib.load().ctr_mlp_head_bwd, x0.data_ptr(), _ld(x0), m, arr, len(layers),

@@ -438,9 +438,13 @@ typedef struct ctr_head_fold_grad {
   float* gb2;           /* (1) or NULL */
   int32_t p, n, k, reserved;
 } ctr_head_fold_grad_t;
+/* zero_buf (nullable; 16-byte aligned, zero_floats a multiple of 4): cleared by the first launch of the call, before
+ * anything accumulates -- the buffer the (+=) outputs of this step live in (torch's optimizer.zero_grad / the fill
+ * launch in front of the backward).  On CTR_ELIMIT nothing was enqueued and nothing was cleared. */
 int ctr_embed_mlp_head_bwd(const ctr_field_t* fields, int nfields, int64_t batch, const ctr_mlp_layer_t* layers,
                            int nlayers, const ctr_mlp_head_grad_t* hg, const ctr_head_fold_grad_t* fold /*nullable*/,
-                           float* gx, int64_t ldgx, float* workspace, int64_t workspace_floats, void* stream);
+                           float* gx, int64_t ldgx, float* workspace, int64_t workspace_floats,
+                           float* zero_buf /*nullable*/, int64_t zero_floats, void* stream);
 /* gy: gradient of the LAST layer's output; gx (nullable): gradient of x.  workspace is
  * required: (number of workgroups <= 256) * sum_i (n_i*k_i + n_i) floats. */
 int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,

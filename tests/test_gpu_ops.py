@@ -523,13 +523,16 @@ def test_gather_inside_the_tower_forward_matches_the_two_launches(ops, m):
     # fold_grad=...: ctr_fold_head_bwd inside the reduction launch of the same call, against the separate launch
     def fold_grads(fused):
         params = [l.weight for l in layers] + [l.bias for l in layers]
-        zeros = ops.zero_grads(params + [wz, c.new_empty(4), u_full, pw, pb, b2])
+        zeros = ops.zero_grads(params + [wz, c.new_empty(4), u_full, pw, pb, b2], lazy=fused)
+        flat = zeros.pop("flat", None)     # fused: NOT cleared here -- the call's first launch clears it (zero=)
+        if flat is not None:
+            flat.fill_(float("nan"))
         gwh, gch = zeros[id(wz)], list(zeros.values())[2 * len(layers) + 1][:1]   # (the c.new_empty(4) slot)
         gu, gpw, gpb, gb2 = zeros[id(u_full)], zeros[id(pw)], zeros[id(pb)], zeros[id(b2)]
         gbuf = torch.empty((m, 192), device=DEV)
         fg = (u_full, pw, pb, gu, gpw, gpb, gb2) if fused else None
         assert ops.mlp_head_bwd(acts, layers, head, head.out, gprob, gbuf[:, 128:192], gwh, gch, gbuf[:, :128], zeros,
-                                gather_specs=specs, fold_grad=fg) is not None
+                                gather_specs=specs, fold_grad=fg, zero=flat) is not None
         if not fused:
             ops.fold_head_bwd(u_full, 64, pw, pb, gwh, gch, gu, gpw, gpb, gb2)
         return [gwh, gch, gu, gpw, gpb, gb2]
