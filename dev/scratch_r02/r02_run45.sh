@@ -1,7 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out/r02
-for w in 3 2; do
-CTR_NCF16_FWD_WGS=$w timeout -k 10 300 python bench.py --no-gather-leg --no-cpu-baseline --steps 50 --warmup 10 > gpurun_out/r02/bench_z.json 2> gpurun_out/r02/bench_z.err || tail -5 gpurun_out/r02/bench_z.err
+for w in 3 2 3 2; do
+CTR_NCF16_FWD_WGS=$w timeout -k 10 300 python bench.py --no-gather-leg --no-cpu-baseline --steps 100 --warmup 10 > gpurun_out/r02/bench_z.json 2> gpurun_out/r02/bench_z.err || tail -5 gpurun_out/r02/bench_z.err
 python - <<PY
 import json
 d = json.load(open("gpurun_out/r02/bench_z.json"))
