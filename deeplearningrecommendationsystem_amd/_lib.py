@@ -15,7 +15,7 @@ import torch  # noqa: F401  (maps libamdhip64 first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTRHIP_LIB", os.path.join(_HERE, "libctrhip.so"))  # env override: A/B builds
-ABI_VERSION = 26
+ABI_VERSION = 27
 DIN_TRIPLE, DIN_PAIR, DIN_H = 0, 1, 2  # layouts of the DIN attention operand (include/ctrhip.h)
 
 CTR_MAX_FIELDS = 32
@@ -98,8 +98,6 @@ SIGNATURES = {
     "ctr_target_arch": (C.c_char_p, []),
     "ctr_embed_fwd": (_i, [C.POINTER(Field), _i, _p, _l, _l, _p, _l, _p, _p]),
     "ctr_embed_bwd": (_i, [C.POINTER(Field), _i, _p, _l, _l, _p, _l, _p, _l, _p]),
-    "ctr_embed_bwd_presort": (_i, [C.POINTER(Field), _i, _p, _l, _l, _l, _p, _l, _p]),
-    "ctr_embed_bwd_presorted": (_i, [C.POINTER(Field), _i, _p, _l, _l, _p, _l, _p, _l, _p]),
     "ctr_mf_fwd": (_i, [_p, _l, _p, _l, _i, _p, _p, _l, _p, _p, _p]),
     "ctr_mf_bwd": (_i, [_p, _l, _p, _l, _i, _p, _p, _l, _p, _p, _p, _p, _p]),
     "ctr_linear_fwd": (_i, [_p, _l, _p, _l, _p, _p, _l, _p, _l, _l, _i, _i, _i, _p]),

@@ -119,6 +119,8 @@ struct CtrHeadFoldGrad {
 int ctr_reduce_segments_fold(const float* ws, int parts, int64_t stride, const CtrSegments& segs, int64_t head_off,
                              const CtrHeadFoldGrad& fold, hipStream_t st);
 
+int ctr_zero_fill(float* p, int64_t n, hipStream_t st);   // reduce.hip: p 16-byte aligned, n % 4 == 0
+
 // mlp_mfma16.hip: the pinned NeuralCF tower + 64-column head with activations in matrix-core operand layout
 // (CTR_ELIMIT: shape / alignment not taken, nothing enqueued)
 int ctr_ncf16_fwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, const ctr_mlp_head_t* head,
@@ -137,7 +139,7 @@ bool ctr_n1_supported(int k);
 // embed_sorted.hip: sorted segmented-reduce backward for small tables (see there)
 int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch,
                          const float* gout, int64_t ldo, float* workspace, int64_t workspace_floats,
-                         int64_t* used_floats, unsigned char* handled, hipStream_t st, int phase = 0);
+                         int64_t* used_floats, unsigned char* handled, hipStream_t st);
 // embed_bag.hip: bag-table gradients by register accumulation per output column (see there)
 int ctr_embed_bwd_bags(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch,
                        const float* gout, int64_t ldo, float* workspace, int64_t workspace_floats,

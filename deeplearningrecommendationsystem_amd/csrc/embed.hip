@@ -601,8 +601,7 @@ extern "C" int ctr_embed_fwd(const ctr_field_t* fields, int nfields, const float
 }
 
 static int embed_bwd_impl(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch,
-                          const float* gout, int64_t ldo, float* workspace, int64_t workspace_floats, void* stream,
-                          int phase) {
+                          const float* gout, int64_t ldo, float* workspace, int64_t workspace_floats, void* stream) {
   CTR_REQUIRE(batch >= 0, CTR_EINVAL);
   if (batch == 0) return CTR_OK;
   CTR_REQUIRE(ldo > 0, CTR_EINVAL);
@@ -615,7 +614,7 @@ static int embed_bwd_impl(const ctr_field_t* fields, int nfields, const float* x
   unsigned char handled[CTR_MAX_FIELDS];
   int64_t sort_floats = 0, bag_floats_used = 0;
   rc = ctr_embed_bwd_sorted(fields, nfields, x, ldx, batch, gout, ldo, workspace, workspace_floats, &sort_floats,
-                            handled, st, phase);
+                            handled, st);
   if (rc != CTR_OK) return rc;
   workspace_floats -= sort_floats;  // the sort buffers sit at the end
   {  // nothing taken by the sorted path and every field an id column of one (B,F) matrix: the lean scatter
@@ -688,30 +687,5 @@ static int embed_bwd_impl(const ctr_field_t* fields, int nfields, const float* x
 extern "C" int ctr_embed_bwd(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch,
                              const float* gout, int64_t ldo, float* workspace, int64_t workspace_floats,
                              void* stream) {
-  return embed_bwd_impl(fields, nfields, x, ldx, batch, gout, ldo, workspace, workspace_floats, stream, 0);
-}
-
-// The part of ctr_embed_bwd that only needs the ids -- the counting sort of the small tables' samples by row --
-// enqueued on its own, e.g. on a side stream while the forward runs.  `ldo` is the leading dimension the gradient
-// matrix will have.  The result stays in `workspace` for ctr_embed_bwd_presorted (same fields apart from the
-// gradient pointers, same x / batch / ldo / workspace and size); nothing else may use the workspace in between.
-extern "C" int ctr_embed_bwd_presort(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch,
-                                     int64_t ldo, float* workspace, int64_t workspace_floats, void* stream) {
-  CTR_REQUIRE(batch >= 0, CTR_EINVAL);
-  if (batch == 0) return CTR_OK;
-  CTR_REQUIRE(ldo > 0 && workspace && workspace_floats > 0, CTR_EINVAL);
-  Plan plan;
-  int rc = make_plan(fields, nfields, x, ldx, workspace /* alignment stand-in for gout */, ldo, true, &plan);
-  if (rc != CTR_OK) return rc;
-  unsigned char handled[CTR_MAX_FIELDS];
-  int64_t sort_floats = 0;
-  return ctr_embed_bwd_sorted(fields, nfields, x, ldx, batch, nullptr, ldo, workspace, workspace_floats, &sort_floats,
-                              handled, (hipStream_t)stream, 1);
-}
-
-extern "C" int ctr_embed_bwd_presorted(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx,
-                                       int64_t batch, const float* gout, int64_t ldo, float* workspace,
-                                       int64_t workspace_floats, void* stream) {
-  CTR_REQUIRE(workspace && workspace_floats > 0, CTR_EINVAL);
-  return embed_bwd_impl(fields, nfields, x, ldx, batch, gout, ldo, workspace, workspace_floats, stream, 2);
+  return embed_bwd_impl(fields, nfields, x, ldx, batch, gout, ldo, workspace, workspace_floats, stream);
 }

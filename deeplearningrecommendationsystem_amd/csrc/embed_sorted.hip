@@ -291,20 +291,13 @@ struct Key {
 // handled[i] is 1 for a field taken completely, 2 / 3 for a PROD field whose first / second
 // factor alone was taken (never happens today: both or none), 0 otherwise.  The sort buffers
 // are carved from the END of the workspace (embed.hip's bag partials use its start).
-//
-// phase 0: sort and reduce.  phase 1 (ctr_embed_bwd_presort): the sort alone, e.g. on a side stream while the
-// forward runs -- it only needs the ids.  phase 2 (ctr_embed_bwd_presorted): the reduce over buffers phase 1 left in
-// the same workspace.  In phases 1 and 2 the set of sort jobs and the workspace layout depend on the fields' kinds,
-// shapes and id columns only, never on the gradient pointers (phase 1 has none): both phases derive the same
-// layout, and a field without gradient simply gets no reduce stream.
 int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch,
                          const float* gout, int64_t ldo, float* workspace, int64_t workspace_floats,
-                         int64_t* used_floats, unsigned char* handled, hipStream_t st, int phase) {
+                         int64_t* used_floats, unsigned char* handled, hipStream_t st) {
   *used_floats = 0;
   for (int i = 0; i < nfields; ++i) handled[i] = 0;
-  const bool ghost = phase != 0;
   if (!workspace || batch >= (1ll << 31) || ldo % 4 != 0) return CTR_OK;
-  if (phase != 1 && !ctr_aligned16(gout)) return CTR_OK;
+  if (!ctr_aligned16(gout)) return CTR_OK;
   SortJobs J;
   Streams T;
   J.n = 0;
@@ -324,7 +317,7 @@ int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x,
     const bool shape_ok = f.width % 4 == 0 && f.out_col % 4 == 0 && f.width <= 256;
     if (!shape_ok) continue;
     const bool g1 = f.grad && ctr_aligned16(f.grad), g2 = f.grad2 && ctr_aligned16(f.grad2);
-    if ((f.kind == CTR_FIELD_ID_I64 || f.kind == CTR_FIELD_ID_F32) && (ghost || g1) && small(f.vocab)) {
+    if ((f.kind == CTR_FIELD_ID_I64 || f.kind == CTR_FIELD_ID_F32) && g1 && small(f.vocab)) {
       if (vstreams + 1 > kMaxStreams) continue;
       const int before = J.n;
       const int jb = f.kind == CTR_FIELD_ID_I64 ? job_of(f.idx, f.idx_stride, f.vocab)
@@ -344,7 +337,7 @@ int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x,
         T.s[T.n++] = Stream{jb, f.width, f.out_col, pow2_ceil(f.width / 4), f.grad, nullptr, nullptr, 0, 0, 0};
         handled[i] = 1;
       }
-    } else if (f.kind == CTR_FIELD_PROD_I64 && (ghost || (g1 && g2)) && small(f.vocab) && small(f.vocab2) &&
+    } else if (f.kind == CTR_FIELD_PROD_I64 && g1 && g2 && small(f.vocab) && small(f.vocab2) &&
                ctr_aligned16(f.table) && ctr_aligned16(f.table2)) {
       if (vstreams + 2 > kMaxStreams) continue;
       const int n0 = J.n;
@@ -387,7 +380,7 @@ int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x,
       }
     }
   }
-  if (J.n == 0 || (phase != 1 && T.n == 0)) {
+  if (J.n == 0 || T.n == 0) {
     for (int i = 0; i < nfields; ++i) handled[i] = 0;
     return CTR_OK;
   }
@@ -427,31 +420,19 @@ int ctr_embed_bwd_sorted(const ctr_field_t* fields, int nfields, const float* x,
     maxv = J.j[k].vocab > maxv ? J.j[k].vocab : maxv;
   }
   *used_floats = need;
-  if (phase != 2) {
   hipLaunchKernelGGL(sort_count_kernel, dim3(nblk, J.n), dim3(kBlock), sizeof(int) * maxv, st, J, (uint32_t)batch,
                      (uint32_t)chunk);
   hipLaunchKernelGGL(sort_colscan_kernel, dim3((unsigned)ctr_ceil_div(maxv, kBlock), J.n), dim3(kBlock), 0, st, J, nblk);
   hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblk, J.n), dim3(kBlock), sizeof(int) * maxv, st, J, (uint32_t)batch,
                      (uint32_t)chunk);
-  }
-  if (phase == 1) return ctr_launch_status();
   // grid.x sized for the narrowest stream's groups-per-workgroup; wider streams exit early
   int maxlpr = 1;
   for (int k = 0; k < T.n; ++k) maxlpr = T.s[k].lpr > maxlpr ? T.s[k].lpr : maxlpr;
   // sorted samples per lane group: 8 (A/B on MI355X, NeuralCF step: 16 -> 181.3 us, 8 -> 177.2 us, 4 -> 177.6 us)
-  static const int run = [] {
-    const char* e = getenv("CTR_SEG_RUN");
-    const int v = e ? atoi(e) : kRunDefault;
-    return v == 4 || v == 16 ? v : 8;
-  }();
+  constexpr int run = kRunDefault;
   const int64_t groups = ctr_ceil_div(batch, run);
   const int gx = (int)ctr_ceil_div(groups, kBlock / maxlpr);
   const dim3 grid(gx, T.n);
-  if (run == 4)
-    hipLaunchKernelGGL(seg_reduce_kernel<4>, grid, dim3(kBlock), 0, st, J, T, (uint32_t)batch, gout, ldo);
-  else if (run == 16)
-    hipLaunchKernelGGL(seg_reduce_kernel<16>, grid, dim3(kBlock), 0, st, J, T, (uint32_t)batch, gout, ldo);
-  else
-    hipLaunchKernelGGL(seg_reduce_kernel<8>, grid, dim3(kBlock), 0, st, J, T, (uint32_t)batch, gout, ldo);
+  hipLaunchKernelGGL(seg_reduce_kernel<run>, grid, dim3(kBlock), 0, st, J, T, (uint32_t)batch, gout, ldo);
   return ctr_launch_status();
 }

@@ -411,7 +411,7 @@ static int launch_dx(const float* w, int64_t ldw, const float* y, int64_t ldy, c
   const int64_t ny = ctr_ceil_div(k, 32 * nt);
   // rounded down: a workgroup beyond the resident ones would start a second round.  Two per CU with a Y tile in the
   // ring (72 KB of LDS); without one (48 KB, <= 144 registers) three fit
-  static const int wgs_plain = [] { const char* e = getenv("CTR_DX_WGS"); return e && e[0] == '2' ? 2 : 3; }();
+  constexpr int wgs_plain = 3;
   int64_t gx_ = 256 * (act == CTR_ACT_NONE ? wgs_plain : 2) / ny;
   if (gx_ > mtiles) gx_ = mtiles;
   if (gx_ < 1) gx_ = 1;

@@ -293,221 +293,15 @@ gru16_bwd_kernel(int64_t batch, int len, const float* __restrict__ gi, int64_t l
   }
 }
 
-// ---- E = 16 with the input projection inside (ctr_gru_fused_fwd / _bwd) -------------------------------------------
+// ---- E = 16 with the input projection inside (ctr_gru_fused_fwd / _bwd): the matrix-core kernels further down.
 // gi = X W_ih^T + b_ih as a GEMM writes and re-reads 3E floats per step and sample (629 MB each way at the DIEN
-// config), and its backward is three more passes (dX, dW_ih, dW_hh) over dgi / dgh of the same size.  Here lane j also
-// keeps rows j, 16+j, 32+j of W_ih: the projection of step t+1 does not depend on the state, so its 48 FMAs fill the
-// issue slots the dependent chain of step t leaves empty.  Backward: the same recomputation, the input gradient
-// dX_t = W_ih^T dgi_t from W_ih's columns (sharing the broadcasts of the W_hh^T product), and dW_ih / dW_hh / the
-// biases accumulated in registers over every (sample, step) a lane group walks -- row j, 16+j, 32+j of each, as
-// dgate_j * x_k and dgate_j * h_{t-1,k} with the broadcasts of x and h the forward recomputation needed anyway.
-// Nothing of size 3E per step is stored.  A workgroup's 16 groups meet in LDS and leave one partial in the
-// workspace (reduce_segments sums them).
+// config), and its backward is three more passes (dX, dW_ih, dW_hh) over dgi / dgh of the same size; the fused
+// kernels store nothing of size 3E per step.  One partial per workgroup goes to the workspace (reduce_segments).
+// (Round 2 also had a DPP-row form of the fused kernels -- four samples per wave, 775 us against 365 us backward;
+// retired in round 3.  The independent cross-check of the fused path is the GEMM decomposition above.)
 constexpr int kGruSlab = 2 * 48 * 16 + 2 * 48;   // dW_ih, dW_hh, db_ih, db_hh
 
-__global__ void __launch_bounds__(kBlock)
-gru16_fused_fwd_kernel(int64_t batch, int len, const float* __restrict__ x, int64_t ldx, const float* __restrict__ w_ih,
-                       const float* __restrict__ b_ih, const float* __restrict__ w_hh, const float* __restrict__ b_hh,
-                       float* __restrict__ hbuf, float* __restrict__ last, int64_t ldl) {
-  constexpr int E = 16;
-  const int j = threadIdx.x & 15;
-  float wr[E], wz[E], wn[E], ur[E], uz[E], un[E];
-#pragma unroll
-  for (int k = 0; k < E; ++k) {
-    wr[k] = w_hh[j * E + k];
-    wz[k] = w_hh[(E + j) * E + k];
-    wn[k] = w_hh[(2 * E + j) * E + k];
-    ur[k] = w_ih[j * E + k];
-    uz[k] = w_ih[(E + j) * E + k];
-    un[k] = w_ih[(2 * E + j) * E + k];
-  }
-  const float br = b_hh[j], bz = b_hh[E + j], bn = b_hh[2 * E + j];
-  const float cr0 = b_ih[j], cz0 = b_ih[E + j], cn0 = b_ih[2 * E + j];
-  const int64_t stride = (int64_t)gridDim.x * (kBlock / E);
-  for (int64_t b = (int64_t)blockIdx.x * (kBlock / E) + (threadIdx.x >> 4); b < batch; b += stride) {
-    float h = 0.0f;
-    hbuf[b * (len + 1) * E + j] = 0.0f;
-    const float* xs = x + (b * len) * ldx + j;
-    // x of four steps at a time, one block ahead of the block whose projections are being formed
-    float xc[4], xq[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) xc[u] = u < len ? ctr_ldg(xs + (int64_t)u * ldx) : 0.0f;
-    float gr = cr0, gz = cz0, gn = cn0;                // input projection of step t
-    {
-      float x0 = xc[0];
-      settle(x0);
-#define CTR_STEP(K) { fmac_bcast<K>(gr, x0, ur[K]); fmac_bcast<K>(gz, x0, uz[K]); fmac_bcast<K>(gn, x0, un[K]); }
-      CTR_ROW16(CTR_STEP)
-#undef CTR_STEP
-    }
-    for (int t0 = 0; t0 < len; t0 += 4) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) xq[u] = t0 + 4 + u < len ? ctr_ldg(xs + (int64_t)(t0 + 4 + u) * ldx) : 0.0f;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int t = t0 + u;
-        if (t >= len) break;
-        float x1 = u < 3 ? xc[u < 3 ? u + 1 : 0] : xq[0];   // x_{t+1}
-        float nr = cr0, nz = cz0, nn = cn0;              // projection of step t+1: independent of h
-        settle(x1);
-#define CTR_STEP(K) { fmac_bcast<K>(nr, x1, ur[K]); fmac_bcast<K>(nz, x1, uz[K]); fmac_bcast<K>(nn, x1, un[K]); }
-        CTR_ROW16(CTR_STEP)
-#undef CTR_STEP
-        float ar = br, az = bz, an = bn;
-        settle(h);
-#define CTR_STEP(K) { fmac_bcast<K>(ar, h, wr[K]); fmac_bcast<K>(az, h, wz[K]); fmac_bcast<K>(an, h, wn[K]); }
-        CTR_ROW16(CTR_STEP)
-#undef CTR_STEP
-        const float r = ctr_sigmoid(gr + ar);
-        const float z = ctr_sigmoid(gz + az);
-        const float n = tanhf(gn + r * an);
-        h = (1.0f - z) * n + z * h;
-        hbuf[(b * (len + 1) + t + 1) * E + j] = h;
-        gr = nr; gz = nz; gn = nn;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) xc[u] = xq[u];
-    }
-    if (last) last[b * ldl + j] = h;
-  }
-}
-
 typedef float gru_f32x4 __attribute__((ext_vector_type(4)));
-
-__global__ void __launch_bounds__(kBlock)
-gru16_fused_bwd_kernel(int64_t batch, int len, const float* __restrict__ x, int64_t ldx, const float* __restrict__ w_ih,
-                       const float* __restrict__ b_ih, const float* __restrict__ w_hh, const float* __restrict__ b_hh,
-                       const float* __restrict__ hbuf, const float* __restrict__ glast, int64_t ldgl,
-                       float* __restrict__ gx, int64_t ldgx, float* __restrict__ ws) {
-  constexpr int E = 16;
-  __shared__ float s_part[kBlock / 64][kGruSlab];   // one slab per wave, summed on the way out
-  const int j = threadIdx.x & 15;
-  float wr[E], wz[E], wn[E];     // rows j, 16+j, 32+j of W_hh: the forward dots
-  float cr[E], cz[E], cn[E];     // column j of the three gate blocks of W_hh: W_hh^T dgh
-  float ur[E], uz[E], un[E];     // rows of W_ih: the input projection again
-  float vr[E], vz[E], vn[E];     // column j of W_ih's gate blocks: dX = W_ih^T dgi
-#pragma unroll
-  for (int k = 0; k < E; ++k) {
-    wr[k] = w_hh[j * E + k];
-    wz[k] = w_hh[(E + j) * E + k];
-    wn[k] = w_hh[(2 * E + j) * E + k];
-    cr[k] = w_hh[k * E + j];
-    cz[k] = w_hh[(E + k) * E + j];
-    cn[k] = w_hh[(2 * E + k) * E + j];
-    ur[k] = w_ih[j * E + k];
-    uz[k] = w_ih[(E + j) * E + k];
-    un[k] = w_ih[(2 * E + j) * E + k];
-    vr[k] = w_ih[k * E + j];
-    vz[k] = w_ih[(E + k) * E + j];
-    vn[k] = w_ih[(2 * E + k) * E + j];
-  }
-  const float br = b_hh[j], bz = b_hh[E + j], bn = b_hh[2 * E + j];
-  const float cr0 = b_ih[j], cz0 = b_ih[E + j], cn0 = b_ih[2 * E + j];
-  // dW_ih / dW_hh as matrix-core accumulators: a wave's four samples are the four contraction indices of
-  // v_mfma_f32_16x16x4_f32 -- lane (sample, unit) IS the A layout for the gate gradients and the B layout for x / h --
-  // so one instruction per gate block adds the four outer products dgate_s (x) x_s (register FMAs for this were 96
-  // per step on accumulators that no longer fit the 256 architectural registers).
-  // D layout: lane (q, c) register r = element [4q + r][c] of the 16 x 16 block.
-  gru_f32x4 mi[3], mh[3];
-#pragma unroll
-  for (int g = 0; g < 3; ++g) mi[g] = mh[g] = gru_f32x4{0.f, 0.f, 0.f, 0.f};
-  float sbr = 0.0f, sbz = 0.0f, sbn = 0.0f, sbhn = 0.0f;   // db_ih = (dar, daz, dan), db_hh = (dar, daz, dhn)
-  const int64_t stride = (int64_t)gridDim.x * (kBlock / E);
-  for (int64_t b = (int64_t)blockIdx.x * (kBlock / E) + (threadIdx.x >> 4); b < batch; b += stride) {
-    float dh = glast[b * ldgl + j];
-    const float* xs = x + (b * len) * ldx + j;
-    const float* hs = hbuf + (b * (len + 1)) * E + j;
-    // inputs of four steps at a time, one block ahead: with one wave per SIMD (282 registers) nothing else hides
-    // a load, and a single step (~1 us) is shorter than the memory latency under load
-    float xc[4], hc[4], xq[4], hq[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int tt = len - 1 - u;
-      xc[u] = tt >= 0 ? ctr_ldg(xs + (int64_t)tt * ldx) : 0.0f;
-      hc[u] = tt >= 0 ? ctr_ldg(hs + (int64_t)tt * E) : 0.0f;
-    }
-    for (int thi = len - 1; thi >= 0; thi -= 4) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int tt = thi - 4 - u;
-        xq[u] = tt >= 0 ? ctr_ldg(xs + (int64_t)tt * ldx) : 0.0f;
-        hq[u] = tt >= 0 ? ctr_ldg(hs + (int64_t)tt * E) : 0.0f;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-      const int t = thi - u;
-      if (t < 0) break;
-      float xt = xc[u], hp = hc[u];
-      settle(xt);
-      settle(hp);
-      float gr = cr0, gz = cz0, gn = cn0, ar = br, az = bz, an = bn;
-#define CTR_STEP(K) { fmac_bcast<K>(gr, xt, ur[K]); fmac_bcast<K>(gz, xt, uz[K]); fmac_bcast<K>(gn, xt, un[K]); \
-                      fmac_bcast<K>(ar, hp, wr[K]); fmac_bcast<K>(az, hp, wz[K]); fmac_bcast<K>(an, hp, wn[K]); }
-      CTR_ROW16(CTR_STEP)
-#undef CTR_STEP
-      const float r = ctr_sigmoid(gr + ar);
-      const float z = ctr_sigmoid(gz + az);
-      const float n = tanhf(gn + r * an);
-      const float dz = dh * (hp - n);
-      const float dn = dh * (1.0f - z);
-      float dan = dn * (1.0f - n * n);
-      float dar = dan * an * r * (1.0f - r);
-      float daz = dz * z * (1.0f - z);
-      float dhn = dan * r;
-      settle(dar, daz, dhn, dan);
-      mi[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(dar, xt, mi[0], 0, 0, 0);
-      mi[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(daz, xt, mi[1], 0, 0, 0);
-      mi[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(dan, xt, mi[2], 0, 0, 0);
-      mh[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(dar, hp, mh[0], 0, 0, 0);
-      mh[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(daz, hp, mh[1], 0, 0, 0);
-      mh[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(dhn, hp, mh[2], 0, 0, 0);
-      sbr += dar; sbz += daz; sbn += dan; sbhn += dhn;
-      // dh_{t-1}[j] = dh_t[j]*z + sum_i W_hh[i][j] dgh_t[i];   dX_t[j] = sum_i W_ih[i][j] dgi_t[i]
-      float acc = dh * z, gxj = 0.0f;
-      // (three partial sums each: a 48-long dependent chain would be the step's critical path)
-      float acc1 = 0.0f, acc2 = 0.0f, gx1 = 0.0f, gx2 = 0.0f;
-#define CTR_STEP(K) { fmac_bcast<K>(acc, dar, cr[K]); fmac_bcast<K>(acc1, daz, cz[K]); fmac_bcast<K>(acc2, dhn, cn[K]); \
-                      fmac_bcast<K>(gxj, dar, vr[K]); fmac_bcast<K>(gx1, daz, vz[K]); fmac_bcast<K>(gx2, dan, vn[K]); }
-      CTR_ROW16(CTR_STEP)
-#undef CTR_STEP
-      acc += acc1 + acc2;
-      gxj += gx1 + gx2;
-      gx[(b * len + t) * ldgx + j] = gxj;
-      dh = acc;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        xc[u] = xq[u];
-        hc[u] = hq[u];
-      }
-    }
-  }
-  // wave partial -> LDS slab [dW_ih 48x16 | dW_hh 48x16 | db_ih 48 | db_hh 48], the four waves summed in wave order
-  const int wave = threadIdx.x >> 6, q = (threadIdx.x >> 4) & 3;
-  float* mine = s_part[wave];
-#pragma unroll
-  for (int g = 0; g < 3; ++g)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      mine[(g * E + 4 * q + r) * E + j] = mi[g][r];
-      mine[768 + (g * E + 4 * q + r) * E + j] = mh[g][r];
-    }
-  // biases: the wave's four samples fold by shuffle (lanes j, 16+j, 32+j, 48+j)
-  float bs[4] = {sbr, sbz, sbn, sbhn};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    bs[i] += __shfl_xor(bs[i], 16, 64);
-    bs[i] += __shfl_xor(bs[i], 32, 64);
-  }
-  if (q == 0) {
-    mine[1536 + j] = bs[0]; mine[1536 + E + j] = bs[1]; mine[1536 + 2 * E + j] = bs[2];
-    mine[1584 + j] = bs[0]; mine[1584 + E + j] = bs[1]; mine[1584 + 2 * E + j] = bs[3];
-  }
-  __syncthreads();
-  float* out = ws + (int64_t)blockIdx.x * kGruSlab;
-  for (int i = threadIdx.x; i < kGruSlab; i += kBlock)
-    out[i] = (s_part[0][i] + s_part[1][i]) + (s_part[2][i] + s_part[3][i]);
-}
 
 // ---- E = 16 on the matrix cores: sixteen samples per wave ------------------------------------------------------------
 // The DPP kernels above spend a step's time issuing 96-192 broadcast FMAs for FOUR samples.  As a matrix product the
@@ -857,7 +651,7 @@ extern "C" int ctr_gru_bwd(const float* gi, int64_t ldgi, const float* w_hh, con
   return ctr_launch_status();
 }
 
-// C ABI (include/ctrhip.h): the GRU with its input projection inside.  dim == 16 and batch % 4 == 0 only (CTR_ELIMIT
+// C ABI (include/ctrhip.h): the GRU with its input projection inside.  dim == 16, 16-byte aligned rows only (CTR_ELIMIT
 // otherwise, nothing enqueued: the caller forms gi with ctr_linear_fwd and uses ctr_gru_fwd / ctr_gru_bwd).
 extern "C" int ctr_gru_fused_fwd(const float* x, int64_t ldx, const float* w_ih, const float* b_ih, const float* w_hh,
                                  const float* b_hh, int64_t batch, int len, int dim, float* hbuf, float* last,
@@ -867,21 +661,12 @@ extern "C" int ctr_gru_fused_fwd(const float* x, int64_t ldx, const float* w_ih,
   CTR_REQUIRE(w_ih && b_ih && w_hh && b_hh && hbuf && (len == 0 || x) && ldx >= dim, CTR_EINVAL);
   CTR_REQUIRE(!last || ldl >= dim, CTR_EINVAL);
   CTR_REQUIRE(dim == 16, CTR_ELIMIT);
-  static const bool dpp = [] { const char* e = getenv("CTR_GRU_DPP"); return e && e[0] == '1'; }();
-  if (!dpp && ldx % 4 == 0 && ctr_aligned16(x) && ctr_aligned16(hbuf)) {
-    // sixteen samples per wave on the matrix cores; any batch (a partial wave repeats its last sample)
-    int64_t grid = ctr_ceil_div(batch, (kBlock / 64) * 16);
-    if (grid > 256 * 4) grid = 256 * 4;
-    hipLaunchKernelGGL(gru16_mfma_fwd_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, batch, len, x,
-                       ldx, w_ih, b_ih, w_hh, b_hh, hbuf, last, ldl);
-    return ctr_launch_status();
-  }
-  CTR_REQUIRE(batch % 4 == 0, CTR_ELIMIT);
-  GruGeom g;
-  int rc = make_geom(batch, len, dim, &g);
-  if (rc != CTR_OK) return rc;
-  hipLaunchKernelGGL(gru16_fused_fwd_kernel, dim3(grid_for(g)), dim3(kBlock), 0, (hipStream_t)stream, batch, len, x, ldx,
-                     w_ih, b_ih, w_hh, b_hh, hbuf, last, ldl);
+  // sixteen samples per wave on the matrix cores; any batch (a partial wave repeats its last sample)
+  CTR_REQUIRE(ldx % 4 == 0 && ctr_aligned16(x) && ctr_aligned16(hbuf), CTR_ELIMIT);
+  int64_t grid = ctr_ceil_div(batch, (kBlock / 64) * 16);
+  if (grid > 256 * 4) grid = 256 * 4;
+  hipLaunchKernelGGL(gru16_mfma_fwd_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, batch, len, x,
+                     ldx, w_ih, b_ih, w_hh, b_hh, hbuf, last, ldl);
   return ctr_launch_status();
 }
 
@@ -895,26 +680,12 @@ extern "C" int ctr_gru_fused_bwd(const float* x, int64_t ldx, const float* w_ih,
   CTR_REQUIRE((len == 0 || (x && gx)) && ldx >= dim && ldgx >= dim && ldgl >= dim, CTR_EINVAL);
   CTR_REQUIRE(dim == 16, CTR_ELIMIT);
   if (len == 0) return CTR_OK;
-  static const bool dpp = [] { const char* e = getenv("CTR_GRU_DPP"); return e && e[0] == '1'; }();
-  const bool mfma = !dpp && ldx % 4 == 0 && ldgx % 4 == 0 && ctr_aligned16(x) && ctr_aligned16(hbuf) && ctr_aligned16(gx);
-  CTR_REQUIRE(mfma || batch % 4 == 0, CTR_ELIMIT);
-  int64_t grid;
-  if (mfma) {
-    grid = ctr_ceil_div(batch, (kBlock / 64) * 16);   // sixteen samples per wave
-    if (grid > 256 * 2) grid = 256 * 2;
-  } else {
-    // one wave per SIMD is what the 280 registers of a lane allow: one workgroup per CU, each lane group walking
-    // batch / (256 * 16) samples
-    grid = ctr_ceil_div(batch, kBlock / 16);
-    if (grid > 256) grid = 256;
-  }
+  CTR_REQUIRE(ldx % 4 == 0 && ldgx % 4 == 0 && ctr_aligned16(x) && ctr_aligned16(hbuf) && ctr_aligned16(gx), CTR_ELIMIT);
+  int64_t grid = ctr_ceil_div(batch, (kBlock / 64) * 16);   // sixteen samples per wave
+  if (grid > 256 * 2) grid = 256 * 2;
   CTR_REQUIRE(workspace && workspace_floats >= grid * kGruSlab, CTR_EINVAL);
-  if (mfma)
-    hipLaunchKernelGGL(gru16_mfma_bwd_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, batch, len, x,
-                       ldx, w_ih, b_ih, w_hh, b_hh, hbuf, glast, ldgl, gx, ldgx, workspace);
-  else
-    hipLaunchKernelGGL(gru16_fused_bwd_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, batch, len, x,
-                       ldx, w_ih, b_ih, w_hh, b_hh, hbuf, glast, ldgl, gx, ldgx, workspace);
+  hipLaunchKernelGGL(gru16_mfma_bwd_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, batch, len, x,
+                     ldx, w_ih, b_ih, w_hh, b_hh, hbuf, glast, ldgl, gx, ldgx, workspace);
   int rc = ctr_launch_status();
   if (rc != CTR_OK) return rc;
   CtrSegments segs;

@@ -1217,345 +1217,6 @@ mlp_bwd_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int
 #endif
 }
 
-// ------------------------------------------------------------------ backward, two waves per row tile
-// The same backward walk with EIGHT waves per workgroup: waves w and w + 4 (which the hardware places on the
-// same SIMD) share one 32-row tile -- its two LDS tiles, its gZ / X operands -- and split everything that is
-// per-tile work between them: the dW accumulator tiles (6 + 6 instead of 12: 96 registers each, so the kernel
-// fits 256 registers and two waves per SIMD), the dX column tiles, the operand prefetch, the bias sums and the
-// fused head's reductions.  Phases are separated by workgroup barriers (all four pairs in lockstep).  What it
-// buys is overlap: with one wave per SIMD the ~364 MFMAs of a tile (23 K cycles) are serialised with ~5.5 K
-// VALU / 900 LDS instructions and every wait (PMC: 31 % of the wave time issuing, 31 % issue-stalled, 38 % parked
-// on waitcnt); the partner's MFMAs now run under a wave's address arithmetic, LDS traffic and waits.
-// Fixed shapes with the fused head only (the BASELINE NeuralCF tower).
-template <int WIDTH>
-__device__ __forceinline__ void pair_issue(float4 (&pre)[8], const float* __restrict__ src, int64_t ld, int64_t row0,
-                                           int64_t m, int lane, int W) {
-  constexpr int kUnits = 8 * WIDTH;  // dwordx4 units of the [32][WIDTH] tile; this wave takes every other 64
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int i = lane + 64 * (2 * u + W);
-    pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < kUnits) {
-      const int rr = i / (WIDTH / 4), c = (i - rr * (WIDTH / 4)) * 4;
-      const int64_t row = row0 + rr < m ? row0 + rr : (m > 0 ? m - 1 : 0);
-      const float4 v = *reinterpret_cast<const float4*>(src + row * ld + c);
-      if (row0 + rr < m) pre[u] = v;
-    }
-  }
-}
-template <int WIDTH>
-__device__ __forceinline__ void pair_commit(const float4 (&pre)[8], float* tile, int stride, int lane, int W) {
-  constexpr int kUnits = 8 * WIDTH;
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int i = lane + 64 * (2 * u + W);
-    if (i < kUnits) {
-      const int rr = i / (WIDTH / 4), c = (i - rr * (WIDTH / 4)) * 4;
-      *reinterpret_cast<float4*>(tile + rr * stride + c) = pre[u];
-    }
-  }
-}
-
-constexpr int kPairWaves = 8, kPairs = 4;
-
-// workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would
-// wait for the operand prefetch issued a moment earlier at every one of the 13 barriers of a tile
-__device__ __forceinline__ void pair_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <class S, int MAXT>
-__global__ void __launch_bounds__(64 * kPairWaves, 2)
-mlp_bwd_pair_kernel(const StackDesc dk, const float* __restrict__ x, int64_t ldx, int64_t m, float* __restrict__ gx,
-                    int64_t ldgx, float* __restrict__ ws, int64_t slab, const HeadBwdDesc hb) {
-  static_assert(S::kFixed && MAXT % 4 == 0, "pinned shapes only; slot pairs are dealt to the two waves alternately");
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ StackDesc s_desc;
-  for (int i = threadIdx.x; i < (int)(sizeof(StackDesc) / 4); i += blockDim.x)
-    reinterpret_cast<uint32_t*>(&s_desc)[i] = reinterpret_cast<const uint32_t*>(&dk)[i];
-  __syncthreads();
-  const StackDesc& d = s_desc;
-  float* s_w = lds;
-  const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int pair = wave & (kPairs - 1), W = wave >> 2;  // W: which wave of the pair
-  using Y = Layout<S, true>;
-  constexpr int sa = Y::sa(), sb = Y::sb(), wfloats = Y::wfloats(), nsum = Y::nsum();
-  constexpr int last = S::kLayers - 1, nl = S::N[last];
-  float* tp = lds + wfloats + pair * 32 * (sa + sb);
-  float* tq = tp + 32 * sa;
-  stage_weights(s_w, d, false);
-
-  floatx16 dw[MAXT / 2];  // this wave's half of the dW accumulator tiles, alive across all row tiles
-#pragma unroll
-  for (int t = 0; t < MAXT / 2; ++t)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) dw[t][e] = 0.0f;
-  // bias-gradient partials: nsum floats per WAVE (each wave sums its 16 rows of every column)
-  float* s_db = lds + wfloats + kPairs * 32 * (sa + sb) + wave * nsum;
-  for (int i = lane0; i < nsum; i += 64) s_db[i] = 0.0f;
-  __shared__ __attribute__((aligned(16))) float s_hwb[kHeadBwdP + kHeadBwdN];
-  float hx_sum = 0.0f, hy_sum = 0.0f, hc_sum = 0.0f;
-  for (int i = threadIdx.x; i < kHeadBwdP + kHeadBwdN; i += blockDim.x) s_hwb[i] = hb.w[i];
-  __syncthreads();
-
-  const int64_t tiles = (m + 31) / 32;
-  const int64_t tstride = (int64_t)gridDim.x * kPairs;
-  const float* xlast = last > 0 ? d.l[last > 0 ? last - 1 : 0].y : x;
-  const int64_t ldxlast = last > 0 ? d.l[last > 0 ? last - 1 : 0].ldy : ldx;
-  float4 pre[8];  // this wave's half of the next layer-input tile, in flight
-  pair_issue<S::K[last]>(pre, xlast, ldxlast, ((int64_t)blockIdx.x * kPairs + pair) * 32, m, lane0, W);
-  // the tile loop has the same trip count for every wave of the workgroup (barriers inside): a pair whose tile
-  // lies past the end walks it with every row masked out
-  for (int64_t t0 = (int64_t)blockIdx.x * kPairs; t0 < tiles; t0 += tstride) {
-    const int64_t tile = t0 + pair;
-    const int64_t row0 = tile * 32;
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));  // lane-derived offsets are re-derived per tile (see mlp_bwd_kernel)
-    const int r = lane & 31, h = lane >> 5;
-    {
-      // fused head: gz per row; wave 0 of the pair writes the tower's gY tile and takes the 16-column groups
-      // c0 = 32h, wave 1 the groups c0 = 32h + 16
-      const int64_t row = row0 + r;
-      const bool ok = row < m;
-      float gz = 0.0f;
-      if (ok) gz = hb.gprob[row * hb.ldgp] * ctr_act_grad(hb.prob[row * hb.ldp], hb.act);
-      if (W == 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) tp[r * sa + 4 * h + q] = gz * s_hwb[kHeadBwdP + 4 * h + q];
-        if (h == 0) hc_sum += gz;
-        float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) yv = *reinterpret_cast<const float4*>(d.l[last].y + row * d.l[last].ldy + 4 * h);
-        float pr[4] = {gz * yv.x, gz * yv.y, gz * yv.z, gz * yv.w};
-        xpose_stage<2>(pr, r & 2, 2);
-        xpose_stage<1>(pr, r & 1, 1);
-        float t = pr[0];
-        t += __shfl_xor(t, 4, 64);
-        t += __shfl_xor(t, 8, 64);
-        t += __shfl_xor(t, 16, 64);
-        hy_sum += t;  // column 4h + (r & 3)
-      }
-      {
-        const int c0 = 32 * h + 16 * W;
-        float pr[16];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-          const float4 wv = *reinterpret_cast<const float4*>(s_hwb + c0 + 4 * i);
-          if (ok) {
-            xv = *reinterpret_cast<const float4*>(hb.xe + row * hb.ldxe + c0 + 4 * i);
-            *reinterpret_cast<float4*>(hb.gxe + row * hb.ldgxe + c0 + 4 * i) =
-                make_float4(gz * wv.x, gz * wv.y, gz * wv.z, gz * wv.w);
-          }
-          pr[4 * i + 0] = gz * xv.x; pr[4 * i + 1] = gz * xv.y; pr[4 * i + 2] = gz * xv.z; pr[4 * i + 3] = gz * xv.w;
-        }
-        xpose_stage<8>(pr, r & 8, 8);
-        xpose_stage<4>(pr, r & 4, 4);
-        xpose_stage<2>(pr, r & 2, 2);
-        xpose_stage<1>(pr, r & 1, 1);
-        hx_sum += pr[0] + __shfl_xor(pr[0], 16, 64);  // column c0 + (r & 15)
-      }
-    }
-    pair_barrier();
-    if (S::ACT[last] != CTR_ACT_NONE && W == 1) {
-      // gZ = gY * act'(Y) of the last layer, in place (a [32][nl <= 8] tile: one wave's worth of work)
-      tile_mask<8, true>(tp, sa, d.l[last].y, d.l[last].ldy, row0, m, nl, d.l[last].div_n, S::ACT[last], lane);
-    }
-    pair_barrier();
-    auto layer = [&](auto lqv) __attribute__((always_inline)) {
-      constexpr int li = last - (int)decltype(lqv)::value;
-      LayerDesc L = d.l[li];
-      pin_shape<S, true>(L, li);
-      constexpr int dboff = Y::db_off(li);
-      constexpr bool even = ((last - li) & 1) == 0;
-      float* gt = even ? tp : tq;      // gZ of this layer
-      float* xt = even ? tq : tp;      // X_l, then dX_l
-      constexpr int gs = even ? sa : sb, xs = even ? sb : sa;
-      constexpr int LN = S::N[li], LK = S::K[li];
-      if (W == 0) {
-        constexpr int npad = (LN + 7) / 8 * 8 - LN;
-        for (int i = lane; i < 32 * npad; i += 64) {
-          const int rr = i / (npad > 0 ? npad : 1), c = i - rr * npad;
-          gt[rr * gs + LN + c] = 0.0f;
-        }
-      }
-      // X_l was requested one layer (or one tile) ago: park this wave's half, request the next operand
-      pair_commit<LK>(pre, xt, xs, lane, W);
-      if constexpr (li > 0) {
-        constexpr int lp = li - 1;
-        const float* nsrc = lp > 0 ? d.l[lp > 0 ? lp - 1 : 0].y : x;
-        const int64_t nld = lp > 0 ? d.l[lp > 0 ? lp - 1 : 0].ldy : ldx;
-        pair_issue<S::K[lp]>(pre, nsrc, nld, row0, m, lane, W);
-      } else {
-        pair_issue<S::K[last]>(pre, xlast, ldxlast, (tile + tstride) * 32, m, lane, W);
-      }
-      pair_barrier();
-      // bias gradient: lane j sums column j of gZ over this wave's 16 rows
-      if (lane < LN) {
-        float t = 0.0f;
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) t += gt[(16 * W + rr) * gs + lane];
-        s_db[dboff + lane] += t;
-      }
-      // dW_l += gZ^T X over the 32 rows: the slot pairs (s2, s2 + 1) go to the two waves alternately
-      {
-        constexpr int nrt = (LN + 31) / 32, nkt = (LK + 31) / 32;
-        constexpr int acc_off = Y::acc_off(li);
-#pragma unroll
-        for (int s2 = 0; s2 < MAXT; s2 += 2) {
-          constexpr int dummy = 0;
-          (void)dummy;
-          const int relA = s2 - acc_off, relB = relA + 1;
-          const bool okA = relA >= 0 && relA < nrt * nkt, okB = relB >= 0 && relB < nrt * nkt;
-          if ((okA || okB) && ((s2 >> 1) & 1) == W) {
-            float faA[16], fbA[16], faB[16], fbB[16];
-            if (okA) {
-              const int it = relA / nkt, jt = relA - it * nkt;
-              read_ks<16>(gt, gs, 32 * it + r, 0, h, faA);
-              read_ks<16>(xt, xs, 32 * jt + r, 0, h, fbA);
-            } else {
-#pragma unroll
-              for (int t = 0; t < 16; ++t) faA[t] = fbA[t] = 0.0f;
-            }
-            if (okB) {
-              const int it = relB / nkt, jt = relB - it * nkt;
-              read_ks<16>(gt, gs, 32 * it + r, 0, h, faB);
-              read_ks<16>(xt, xs, 32 * jt + r, 0, h, fbB);
-            } else {
-#pragma unroll
-              for (int t = 0; t < 16; ++t) faB[t] = fbB[t] = 0.0f;
-            }
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-              dw[(s2 >> 2) * 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(faA[t], fbA[t], dw[(s2 >> 2) * 2], 0, 0, 0);
-              dw[(s2 >> 2) * 2 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(faB[t], fbB[t], dw[(s2 >> 2) * 2 + 1], 0, 0, 0);
-            }
-          }
-        }
-      }
-      // both waves are done reading X_l before anybody writes dX_l over it
-      pair_barrier();
-      {
-        const float* wl = s_w + L.w_off;
-        constexpr int wsd = LK + 4;
-        constexpr int nkt = (LK + 31) / 32;
-        constexpr int act_prev = li > 0 ? S::ACT[li > 0 ? li - 1 : 0] : CTR_ACT_NONE;
-#pragma unroll
-        for (int ct = 0; ct < nkt; ++ct) {
-          if (((ct + li) & 1) != W) continue;  // column tiles dealt to the two waves
-          floatx16 a, a1;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) a[e] = a1[e] = 0.0f;
-          const int col = 32 * ct + r;
-          int base = 0;
-#pragma unroll
-          for (; base + 32 <= LN; base += 32) dx_chunk<16>(gt, gs, wl, wsd, col, base, r, h, a, a1);
-          constexpr int rem = LN % 32;
-          if constexpr (rem > 24) dx_chunk<16>(gt, gs, wl, wsd, col, base, r, h, a, a1);
-          else if constexpr (rem > 16) dx_chunk<12>(gt, gs, wl, wsd, col, base, r, h, a, a1);
-          else if constexpr (rem > 8) dx_chunk<8>(gt, gs, wl, wsd, col, base, r, h, a, a1);
-          else if constexpr (rem > 0) dx_chunk<4>(gt, gs, wl, wsd, col, base, r, h, a, a1);
-#pragma unroll
-          for (int e = 0; e < 16; ++e) a[e] += a1[e];
-          if (col < LK) {
-            if constexpr (li == 0) {
-              if (gx) {
-                float* gp = gx + (row0 + 4 * h) * ldgx + col;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                  const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-                  if (row0 + row < m) ctr_stg(gp + ((e & 3) + 8 * (e >> 2)) * ldgx, a[e]);
-                }
-              }
-            } else {
-              float* q = xt + 4 * h * xs + col;
-              if (act_prev != CTR_ACT_NONE) {
-                float yv[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) yv[e] = q[((e & 3) + 8 * (e >> 2)) * xs];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) a[e] *= ctr_act_grad(yv[e], act_prev);
-              }
-#pragma unroll
-              for (int e = 0; e < 16; ++e) q[((e & 3) + 8 * (e >> 2)) * xs] = a[e];
-            }
-          }
-        }
-      }
-      if constexpr (li > 0) pair_barrier();  // dX_l complete: it is the gZ of layer l - 1
-    };
-    static_layers(layer, std::make_integer_sequence<int, S::kLayers>{});
-  }
-
-  // workgroup partial of dW / db -> one slab in the workspace (see mlp_bwd_kernel): every PAIR stores its tiles
-  // into a copy of its own (the two waves hold disjoint tiles), copies summed in a fixed order on the way out
-  const int lane = lane0, r = lane0 & 31, h = lane0 >> 5;
-  __syncthreads();
-  constexpr int avail = wfloats + kPairs * 32 * (sa + sb);
-  float* s_red = lds;
-  const float* s_dbv = lds + avail;  // the eight waves' bias partials, kept beyond the tiles
-  int off = 0;
-  auto flush = [&](auto liv) __attribute__((always_inline)) {
-    constexpr int li = (int)decltype(liv)::value;
-    constexpr int LN = S::N[li], LK = S::K[li];
-    constexpr int nkt = (LK + 31) / 32, nrt = (LN + 31) / 32;
-    constexpr int cnt = LN * LK + LN;
-    constexpr int copies = 4 * cnt <= avail ? 4 : (2 * cnt <= avail ? 2 : 1);
-    constexpr int acc_off = Y::acc_off(li);
-    float* mine = s_red + (pair & (copies - 1)) * cnt;
-    for (int p = 0; p < kPairs / copies; ++p) {
-      if (pair / copies == p) {
-#pragma unroll
-        for (int s2 = 0; s2 < MAXT; ++s2) {
-          const int rel = s2 - acc_off;
-          if (rel >= 0 && rel < nrt * nkt && ((s2 >> 1) & 1) == W) {
-            const int it = rel / nkt, jt = rel - it * nkt;
-            const int kcol = 32 * jt + r;
-            float* q = mine + (32 * it + 4 * h) * LK + kcol;
-            const floatx16& acc = dw[(s2 >> 2) * 2 + (s2 & 1)];
-            if (kcol < LK) {
-#pragma unroll
-              for (int e = 0; e < 16; ++e) {
-                const int rr = (e & 3) + 8 * (e >> 2);
-                if (32 * it + 4 * h + rr < LN) q[rr * LK] = p == 0 ? acc[e] : q[rr * LK] + acc[e];
-              }
-            }
-          }
-        }
-        if (W == 0) {
-          for (int j = lane; j < LN; j += 64) {
-            const float t = s_dbv[pair * nsum + Y::db_off(li) + j] + s_dbv[(pair + kPairs) * nsum + Y::db_off(li) + j];
-            float* q = mine + LN * LK + j;
-            *q = p == 0 ? t : *q + t;
-          }
-        }
-      }
-      __syncthreads();
-    }
-    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-      float v = s_red[i];
-      for (int c = 1; c < copies; ++c) v += s_red[c * cnt + i];
-      ws[(int64_t)blockIdx.x * slab + off + i] = v;
-    }
-    __syncthreads();
-    off += cnt;
-  };
-  static_layers(flush, std::make_integer_sequence<int, S::kLayers>{});
-  {
-    // the head's sums: every wave parks its share ([pair][80]), the workgroup adds the four pairs in order
-    float* s_h = s_red;
-    if (r < 16) s_h[pair * 80 + 32 * h + 16 * W + r] = hx_sum;
-    if (W == 0) {
-      if (r < 4) s_h[pair * 80 + kHeadBwdP + 4 * h + r] = hy_sum;
-      const float c = ctr_wave_sum(hc_sum);
-      if (lane == 0) s_h[pair * 80 + kHeadBwdP + kHeadBwdN] = c;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < kHeadBwdSums; i += blockDim.x) {
-      float v = s_h[i];
-      for (int w2 = 1; w2 < kPairs; ++w2) v += s_h[w2 * 80 + i];
-      ws[(int64_t)blockIdx.x * slab + off + i] = v;
-    }
-  }
-}
-
 // ------------------------------------------------------------------ host
 struct Built {
   StackDesc d;
@@ -1695,8 +1356,7 @@ static int mlp_fwd_impl(const float* x, int64_t ldx, int64_t m, const ctr_mlp_la
         rc = ctr_ncf16_fwd(x, ldx, m, layers, head, st);
         if (rc != CTR_ELIMIT) return rc;
       }
-      static const bool four = [] { const char* e = getenv("CTR_MLP_FWD_WAVES"); return e && e[0] == '4'; }();
-      if (!four) {  // two waves per SIMD (see mlp_fwd_direct_kernel); CTR_MLP_FWD_WAVES=4 keeps the A/B alive
+      {  // two waves per SIMD (see mlp_fwd_direct_kernel)
         constexpr size_t bytes = DirectLayout<NcfTowerShape>::lds_bytes();
         static_assert(bytes + sizeof(StackDesc) + sizeof(float) * kHeadMax <= 160 * 1024, "eight strips + weights fit the CU");
         rc = allow_lds(mlp_fwd_direct_kernel<NcfTowerShape, true>, bytes);
@@ -1707,10 +1367,6 @@ static int mlp_fwd_impl(const float* x, int64_t ldx, int64_t m, const ctr_mlp_la
                            st, b.d, x, ldx, m, hd);
         return ctr_launch_status();
       }
-      rc = allow_lds(mlp_fwd_kernel<NcfTowerShape, true>, b.lds_bytes);
-      if (rc != CTR_OK) return rc;
-      hipLaunchKernelGGL((mlp_fwd_kernel<NcfTowerShape, true>), dim3((unsigned)grid), dim3(kThreads), b.lds_bytes, st, b.d,
-                         x, ldx, m, hd);
     } else {
       rc = allow_lds(mlp_fwd_kernel<DynShape, true>, b.lds_bytes);
       if (rc != CTR_OK) return rc;
@@ -1836,7 +1492,8 @@ static int mlp_head_bwd_impl(const ctr_field_t* fields, int nfields, const float
                              const ctr_head_fold_grad_t* fold, float* gx, int64_t ldgx, float* workspace,
                              int64_t workspace_floats, void* stream, float* zero_buf = nullptr, int64_t zero_floats = 0) {
   CTR_REQUIRE(m >= 0 && hg, CTR_EINVAL);
-  if (m == 0) return CTR_OK;
+  // an empty batch still owes the caller the cleared gradient buffer (it passed zero_buf INSTEAD of filling it)
+  if (m == 0) return zero_buf ? ctr_zero_fill(zero_buf, zero_floats, (hipStream_t)stream) : CTR_OK;
   CTR_REQUIRE(x && workspace, CTR_EINVAL);
   CTR_REQUIRE(ctr_aligned16(x) && ldx % 4 == 0, CTR_EALIGN);
   CTR_REQUIRE(hg->prob && hg->gprob && hg->x && hg->w && hg->gx && hg->gw && hg->gc, CTR_EINVAL);
@@ -1876,29 +1533,8 @@ static int mlp_head_bwd_impl(const ctr_field_t* fields, int nfields, const float
   }
   if (fields && !done16) return CTR_ELIMIT;   // only the operand-layout kernel gathers
   const HeadBwdDesc hb{hg->gprob, hg->ldgprob, hg->prob, hg->ldprob, hg->x, hg->ldx, hg->w, hg->gx, hg->ldgx, hg->act};
-  // CTR_MLP_PAIR=1 selects the two-waves-per-tile kernel (A/B switch).  Measured on MI355X, batch 65536 (rocprofv3,
-  // profiles/r02_mlp_pair_ab.txt): 73.1 us against 72.3 us for the one-wave-per-tile kernel -- occupancy 2, 201
-  // registers, no scratch, barriers that wait on LDS only (not on the operand prefetch) -- and no gain.  PMC of the
-  // one-wave kernel (profiles/r02_mlp_pmc.txt): per wave 12.0 K VALU + 3.7 K SALU + 1.8 K LDS + 0.16 K VMEM instructions
-  // next to 728 MFMAs; at one issue per ~4 cycles that instruction stream alone is ~70 K cycles beside the 47 K
-  // cycles of MFMA issue: the kernel is bound by instruction ISSUE per SIMD (address arithmetic, accumulator
-  // moves, exec-mask bookkeeping), which two waves on the same SIMD share -- splitting a tile between them moves
-  // instructions from one wave to the other (plus the pair's bookkeeping) and leaves the SIMD's total unchanged.
-  // What has to shrink is the instruction count per tile, not the register footprint.  Kept as an A/B switch.
-  static const bool pair_on = [] {
-    const char* e = getenv("CTR_MLP_PAIR");
-    return e && e[0] == '1';
-  }();
   if (done16) {
     // launched above
-  } else if (pair_on) {
-    // two waves per row tile, eight per workgroup (same tiles per workgroup, same slab layout)
-    const size_t lds_bytes = b.lds_bytes + sizeof(float) * (size_t)(kPairWaves - kWaves) * b.d.nsum;
-    CTR_REQUIRE(lds_bytes + sizeof(StackDesc) <= 160 * 1024, CTR_ELIMIT);
-    rc = allow_lds(mlp_bwd_pair_kernel<NcfTowerShape, 12>, lds_bytes);
-    if (rc != CTR_OK) return rc;
-    hipLaunchKernelGGL((mlp_bwd_pair_kernel<NcfTowerShape, 12>), dim3((unsigned)grid), dim3(64 * kPairWaves), lds_bytes,
-                       st, b.d, x, ldx, m, gx, ldgx, workspace, slab, hb);
   } else {
     if (m % 32 == 0) {  // every tile full (the BASELINE batch): the instantiation without row-range checks
       rc = allow_lds(mlp_bwd_kernel<NcfTowerShape, 12, true, true>, b.lds_bytes);
@@ -1926,7 +1562,7 @@ static int mlp_head_bwd_impl(const ctr_field_t* fields, int nfields, const float
   if (fold) {
     if (fold->p != kHeadBwdP || fold->n != 64 || fold->k != kHeadBwdN || !fold->u_full || !fold->w || fold->ldw < fold->k ||
         (fold->gw && fold->ldgw < fold->k))
-      return CTR_EINVAL;   // (checked before anything was enqueued would be nicer; these are caller bugs, not shapes)
+      return CTR_EINVAL;   // (unreachable from the C ABI: ctr_embed_mlp_head_bwd checks the same before anything is enqueued)
     const CtrHeadFoldGrad F{fold->u_full, fold->w, fold->ldw, fold->b, hg->gw, hg->gc, fold->gu_full, fold->gw, fold->ldgw,
                             fold->gb, fold->gb2};
     return ctr_reduce_segments_fold(workspace, (int)grid, slab, segs, off, F, st);

@@ -952,7 +952,7 @@ static int ncf16_fwd_launch(const float* x, int64_t ldx, int64_t m, const ctr_ml
   const HeadFwd H{head->x, head->ldx, head->w, head->c, head->out, head->ldout, head->act};
   const int64_t groups = ctr_ceil_div(m, 16);
   int64_t grid = ctr_ceil_div(groups, kWaves);
-  static const int wgs = [] { const char* e = getenv("CTR_NCF16_FWD_WGS"); return e ? atoi(e) : 3; }();
+  constexpr int wgs = 3;
   if (grid > 256 * wgs) grid = 256 * wgs;   // three resident workgroups per CU (45 KB of LDS, <= 168 registers)
   if (gather)
     hipLaunchKernelGGL(ncf16_fwd_kernel<true>, dim3((unsigned)grid), dim3(kThreads), 0, st, T, x, ldx, m, H, *gather);

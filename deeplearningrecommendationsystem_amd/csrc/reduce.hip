@@ -47,6 +47,13 @@ reduce_segments_kernel(const float* __restrict__ ws, int parts, int64_t stride, 
   }
 }
 
+__global__ void __launch_bounds__(256)
+zero_fill_kernel(float* __restrict__ p, int64_t n) {   // n % 4 == 0, p 16-byte aligned
+  const ctr_f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024)
+    *reinterpret_cast<ctr_f32x4*>(p + i) = z;
+}
+
 // The head's 73 sums (72 folded weights + the folded bias) of NeuralCF and the chain rule through ctr_fold_head_fwd's
 // map in the SAME launch as the other segments (one extra row of the grid, one workgroup): ctr_fold_head_bwd was a
 // 4.4 us launch of its own behind this one.  gw / gc receive the sums (+=) as any segment's dst would; the fold
@@ -163,5 +170,13 @@ int ctr_reduce_segments_fold(const float* ws, int parts, int64_t stride, const C
   if (gx > 2048) gx = 2048;
   hipLaunchKernelGGL(reduce_segments_fold_kernel, dim3((unsigned)gx, (unsigned)segs.n + 1), dim3(kBlock), 0, st, ws, parts,
                      stride, segs, head_off, fold);
+  return ctr_launch_status();
+}
+
+// a capturable zero fill (a kernel, not hipMemsetAsync: DESIGN.md section 4, hipGraph bullet)
+int ctr_zero_fill(float* p, int64_t n, hipStream_t st) {
+  if (n <= 0) return CTR_OK;
+  CTR_REQUIRE(p && ctr_aligned16(p) && n % 4 == 0, CTR_EALIGN);
+  hipLaunchKernelGGL(zero_fill_kernel, dim3(ctr_stream_grid(n / 4, 256)), dim3(256), 0, st, p, n);
   return ctr_launch_status();
 }

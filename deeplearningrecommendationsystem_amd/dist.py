@@ -21,11 +21,15 @@ HIP one and needs the MI355X library like everything else in this package.
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
+
+
+_DEBUG = os.environ.get("CTR_DIST_DEBUG", "0") == "1"
 
 
 class GradBucket:
@@ -198,8 +202,9 @@ class ExchangePlan:
     __slots__ = ("send_counts", "recv_counts", "perm", "inv", "recv_ids", "n")
 
 
-# id(key tensor) -> (weak reference to it, {sub-key: ExchangePlan}).  Keyed by identity with a liveness check (a
-# WeakKeyDictionary would compare tensors with ==); the entry goes away with the tensor.
+# id(key tensor) -> (weak reference to it, {sub-key: (ExchangePlan, weak references of the other key tensors)}).  Keyed
+# by identity with a liveness check (a WeakKeyDictionary would compare tensors with ==); the entry goes away with the
+# tensor.
 _PLANS: dict = {}
 
 
@@ -215,33 +220,79 @@ def _plans_of(anchor: torch.Tensor, create: bool):
     return plans
 
 
+def _split_key(ids: torch.Tensor, key):
+    """-> (anchor tensor, other key tensors, hashable part).  ``key`` = (anchor, extra): ``extra`` is a tensor, a tuple
+    of tensors and hashables, or a hashable.  EVERY tensor of a key is identified by ``id()`` + ``_version`` AND held
+    by a weak reference that must still point at it when the plan is found again: CPython hands the id of a freed
+    temporary to the next tensor of the same size, and a fresh tensor's version is 0 again."""
+    if key is None:
+        return ids, (), None
+    anchor, extra = key
+    parts = extra if isinstance(extra, tuple) else (extra,)
+    others = tuple(p for p in parts if isinstance(p, torch.Tensor))
+    plain = tuple(("t", id(p), p._version) if isinstance(p, torch.Tensor) else p for p in parts)
+    return anchor, others, plain
+
+
 def exchange_plan(ids: torch.Tensor, module: "ShardedEmbedding", key=None) -> ExchangePlan:
-    """``key`` = (tensor whose identity and version stand for the ids, hashable extra) when ``ids`` itself is a
-    temporary (FFM: ``x[:, 0].long()`` of the feature matrix ``x``); default: the id tensor itself"""
-    anchor, extra = (ids, None) if key is None else key
-    sub = (anchor._version, extra, id(module.group), module.world, module.num_embeddings, tuple(ids.shape))
+    """``key`` = (tensor whose identity and version stand for the ids, extra) when ``ids`` itself is a temporary (FFM:
+    ``x[:, 0].long()`` of the feature matrix ``x``; DIN: ``cat(hist, target)`` keyed by ``(hist, target)``); default:
+    the id tensor itself.
+
+    The cache decides per rank, so every rank must present the same sequence of (cached / fresh) lookups: a rank that
+    hits while a peer misses would skip the collectives the peer enters.  Identical id-tensor lifetimes on all ranks
+    (the usual SPMD loop) guarantee it; ``CTR_DIST_DEBUG=1`` all-reduces the decision and raises on a mismatch.
+    ``_version`` does not see writes through raw pointers (this library's kernels): an id tensor filled by a kernel
+    must be passed as a new tensor object, or the plan dropped with ``forget_plans(tensor)``."""
+    anchor, others, plain = _split_key(ids, key)
+    sub = (anchor._version, plain, id(module.group), module.world, module.num_embeddings, tuple(ids.shape))
     plans = _plans_of(anchor, False)
+    hit = None
     if plans is not None and sub in plans:
-        return plans[sub]
+        plan, refs = plans[sub]
+        if all(r() is t for r, t in zip(refs, others)):
+            hit = plan
+        else:
+            del plans[sub]      # an id() recycled by a new tensor: the old plan is for other ids
     be, group, world = module.backend, module.group, module.world
+    if _DEBUG:
+        mine = torch.tensor([1 if hit is not None else 0, 1], dtype=torch.int64)
+        dist.all_reduce(mine, group=group)
+        if int(mine[0]) not in (0, int(mine[1])):
+            raise RuntimeError("exchange_plan: some ranks found a cached plan and others did not -- the ranks' "
+                               "collective sequences would diverge (keep id-tensor lifetimes identical on all ranks)")
+    if hit is not None:
+        return hit
     flat = ids.reshape(-1).contiguous()
     counts, send_ids, perm, inv = be.bucket(flat, world, module.num_embeddings)
     staged = _host_staged(counts, group)
-    mine = counts[:world].cpu() if staged else counts[:world].contiguous()
+    # per peer: (ids I send it, ids of mine outside the table) -- the second column lets EVERY rank learn that some rank
+    # saw a bad id from the one count exchange, so that all of them raise together instead of one raising and the
+    # others blocking in the next collective until the RCCL timeout
+    mine = torch.stack([counts[:world], counts[world:world + 1].expand(world)], dim=1).contiguous()
+    mine = mine.cpu() if staged else mine
     theirs = torch.empty_like(mine)
     dist.all_to_all_single(theirs, mine, group=group)
-    both = torch.cat([counts.cpu() if staged else counts, theirs]).tolist()   # the one host read of the lookup
-    send_counts, bad, recv_counts = [int(c) for c in both[:world]], int(both[world]), [int(c) for c in both[world + 1:]]
+    both = torch.cat([mine[:, 0], theirs.reshape(-1)]).tolist()                # the one host read of the lookup
+    send_counts = [int(c) for c in both[:world]]
+    recv_counts = [int(c) for c in both[world::2]]
+    bad = sum(int(c) for c in both[world + 1::2])                              # over all ranks (mine is in the diagonal)
     if bad:
-        raise IndexError(f"index out of range in self ({bad} ids outside [0, {module.num_embeddings}))")
+        raise IndexError(f"index out of range in self ({bad} ids outside [0, {module.num_embeddings}) on the ranks "
+                         f"of this group)")
     plan = ExchangePlan()
     plan.send_counts, plan.recv_counts, plan.perm, plan.inv, plan.n = send_counts, recv_counts, perm, inv, flat.numel()
     plan.recv_ids = _exchange(send_ids, send_counts, recv_counts, group).long()   # local rows the peers want
     plans = _plans_of(anchor, True)
     if len(plans) >= 8:
         plans.clear()   # an id tensor modified in place over and over: keep the newest versions only
-    plans[sub] = plan
+    plans[sub] = (plan, tuple(weakref.ref(t) for t in others))
     return plan
+
+
+def forget_plans(anchor: torch.Tensor) -> None:
+    """drop every cached plan keyed by ``anchor`` (after writing new ids into it through a raw pointer)"""
+    _PLANS.pop(id(anchor), None)
 
 
 class _ShardedLookup(torch.autograd.Function):

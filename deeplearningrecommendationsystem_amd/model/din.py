@@ -89,7 +89,7 @@ class SequenceModel(CtrModule):
         ids = torch.cat([hist.reshape(-1), target.reshape(-1)])
         # the concatenation is a temporary: the exchange plan is keyed by the caller's tensors (same, unmodified
         # (hist, target) next epoch -> no bucketing, no id exchange, no host sync)
-        rows = table_module(ids, plan_key=(hist, (id(target), target._version)))
+        rows = table_module(ids, plan_key=(hist, target))   # both held by weak reference: dist._split_key
         pos = torch.arange(batch * (length + 1), device=hist.device, dtype=torch.int64)
         return rows, pos[:batch * length].view(batch, length), pos[batch * length:]
 

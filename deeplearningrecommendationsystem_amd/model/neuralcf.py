@@ -13,11 +13,6 @@ from ..ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, FieldSpec, Layer
 from .._lib import FIELD_ID_I64, FIELD_PROD_I64
 from ._base import CtrModule
 
-# Opt-in (CTR_NCF_OVERLAP_SORT=1): start the id-only half of the embedding backward on a side stream during the
-# forward.  Measured on MI355X with the step captured in a hipGraph: 184.7 us with the parallel branch against
-# 178.1 us without -- the cross-stream edges of the graph cost more than the 19 us of sort they take off the
-# critical path -- so the default is the single-stream order.
-OVERLAP_SORT = os.environ.get("CTR_NCF_OVERLAP_SORT", "0") == "1"
 # The gather of the four embedding rows inside the tower's forward kernel (ctr_embed_mlp_head_fwd) where the library
 # has that kernel (the BASELINE shape); CTR_NCF_FUSED_GATHER=0 keeps the gather launch + tower launch for A/B.
 FUSED_GATHER = os.environ.get("CTR_NCF_FUSED_GATHER", "1") != "0"
@@ -54,12 +49,6 @@ class _NeuralCFFunction(torch.autograd.Function):
         kh = proj_w.shape[1]  # width of h
         buf = torch.empty((batch, l0 + mf + (kh if n_hidden else 0)), dtype=torch.float32, device=gmf_u.device)
         specs = _specs(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i)
-        # opt-in (see OVERLAP_SORT): the counting sort of the embedding backward on a side stream, joined in backward
-        sort_ws = side = None
-        if OVERLAP_SORT and any(ctx.needs_input_grad[4:8]):
-            sort_ws = ops.new_scratch(buf.device)
-            with ops.SideStream(buf.device) as side:
-                ops.embed_bwd_presort(specs, None, batch, buf.stride(0), sort_ws)
         acts = None
         wfold = cfold = None
         if n_hidden and FUSED_GATHER:
@@ -92,7 +81,6 @@ class _NeuralCFFunction(torch.autograd.Function):
         ctx.n_hidden = n_hidden
         if not hasattr(ctx, "regather"):
             ctx.regather = False
-        ctx.sort_ws, ctx.sort_side = sort_ws, side
         ctx.save_for_backward(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i, buf, prob, wfold, *acts[1:-1], *dense)
         return prob
 
@@ -146,10 +134,7 @@ class _NeuralCFFunction(torch.autograd.Function):
         if not folded:
             ops.fold_head_bwd(head_w, mf, proj_w, proj_b, gwfold, gcfold, g_head_w, g_proj_w, g_proj_b, g_head_b)
         tgrads = zeros
-        if ctx.sort_side is not None:
-            ctx.sort_side.join()  # the sort the forward started
-        ops.embed_bwd(_specs(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i), None, batch, gbuf, tgrads,
-                      presorted=ctx.sort_ws)
+        ops.embed_bwd(_specs(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i), None, batch, gbuf, tgrads)
         out = [None, None, None, None] + [tgrads[id(t)] for t in tables]
         for gw, gb in layer_grads:
             out += [gw, gb]

@@ -127,11 +127,6 @@ def _scratch(device) -> torch.Tensor:
     return torch.empty(SCRATCH_FLOATS, dtype=torch.float32, device=device)
 
 
-def new_scratch(device) -> torch.Tensor:
-    """a scratch buffer a caller keeps across launches (``embed_bwd_presort`` -> ``embed_bwd(presorted=)``)"""
-    return _scratch(device)
-
-
 def _mat(t: torch.Tensor, what: str) -> torch.Tensor:
     if t.dim() != 2 or t.dtype != torch.float32 or (t.shape[1] > 1 and t.stride(1) != 1):
         raise ValueError(f"{what}: expected a 2-D float32 tensor with unit inner stride, got "
@@ -205,68 +200,17 @@ def embed_fwd(specs: Sequence[FieldSpec], x: Optional[torch.Tensor], batch: int,
 
 
 def embed_bwd(specs: Sequence[FieldSpec], x: Optional[torch.Tensor], batch: int, gout: torch.Tensor,
-              grads: dict, presorted: Optional[torch.Tensor] = None) -> None:
-    """accumulate into ``grads[id(table)]`` (dense, same shape as the table).  ``presorted``: the workspace
-    ``embed_bwd_presort`` filled for the same specs / batch / row stride of ``gout`` -- the backward then starts at
-    the reduce over the sorted samples."""
+              grads: dict) -> None:
+    """accumulate into ``grads[id(table)]`` (dense, same shape as the table)"""
     gout = _mat(gout, "gout")
     if x is not None:
         x = _mat(x, "x")
     arr = _field_array(specs, grads)
-    ws = presorted if presorted is not None else _scratch(gout.device)  # bag partials + the small-table sort buffers
-    fn = _lib.load().ctr_embed_bwd_presorted if presorted is not None else _lib.load().ctr_embed_bwd
+    ws = _scratch(gout.device)  # bag partials + the small-table sort buffers
     rc = _timed("embed_bwd", lambda: (_embed_bytes(specs, batch, True), 0),
-                fn, arr, len(specs), _lib.ptr(x), _ld(x) if x is not None else 0, batch,
+                _lib.load().ctr_embed_bwd, arr, len(specs), _lib.ptr(x), _ld(x) if x is not None else 0, batch,
                 gout.data_ptr(), _ld(gout), _lib.ptr(ws), ws.numel() if ws is not None else 0, _lib.stream_ptr())
     _lib.check(rc, "ctr_embed_bwd")
-
-
-def embed_bwd_presort(specs: Sequence[FieldSpec], x: Optional[torch.Tensor], batch: int, ldo: int,
-                      workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """the id-only part of ``embed_bwd`` (counting sort of the small tables' samples by row) on the current stream;
-    returns the workspace to hand to ``embed_bwd(..., presorted=)``.  ``ldo``: row stride of the gradient matrix."""
-    if x is not None:
-        x = _mat(x, "x")
-    arr = _field_array(specs, None)
-    dev = specs[0].table.device
-    ws = workspace if workspace is not None else _scratch(dev)
-    rc = _timed("embed_bwd_presort", lambda: (16 * batch * len(specs), 0),
-                _lib.load().ctr_embed_bwd_presort, arr, len(specs), _lib.ptr(x), _ld(x) if x is not None else 0, batch,
-                ldo, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
-    _lib.check(rc, "ctr_embed_bwd_presort")
-    return ws
-
-
-_SIDE_STREAMS: dict = {}
-
-
-class SideStream:
-    """``with SideStream(device) as side: ...`` runs the body's launches on a side HIP stream forked off the current
-    one (they start after everything enqueued so far); ``side.join()`` makes the current stream wait for them.
-    Under hipGraph capture the fork / join become graph edges, i.e. parallel branches.  Tensors the body writes
-    must have been allocated on the current stream before the fork (stream-ordered allocator)."""
-
-    def __init__(self, device):
-        self.device = torch.device(device)
-        self.main = torch.cuda.current_stream(self.device)
-        key = (self.device.index if self.device.index is not None else torch.cuda.current_device())
-        if key not in _SIDE_STREAMS:
-            _SIDE_STREAMS[key] = torch.cuda.Stream(device=self.device)
-        self.side = _SIDE_STREAMS[key]
-        self._ctx = None
-
-    def __enter__(self):
-        self.side.wait_stream(self.main)
-        self._ctx = torch.cuda.stream(self.side)
-        self._ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        self._ctx.__exit__(*exc)
-        return False
-
-    def join(self) -> None:
-        self.main.wait_stream(self.side)
 
 
 def linear_fwd(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], act: int = ACT_NONE,

@@ -3,16 +3,23 @@
 Same class, same two methods, same return values: ``negative_sampling`` -> (users, items, zeros) tensors on
 ``device``; ``negative_sampling2`` -> a pandas frame with columns user_id / item_id / rating.  Like the
 reference, a ``Sampler`` instance ACCUMULATES: a second call appends to the negatives of the first
-(sampler.py:13-14, 26-27).  The draws come from a counter-based generator seeded per call
-(``Sampler(seed=...)``; the reference draws from Python's global ``random``), so the sample is
-reproducible and independent of launch geometry; the distribution is the reference's -- uniform over the
-items of a user that are not in ``excluded_pairs``."""
+(sampler.py:13-14, 26-27).  The draws come from a counter-based generator seeded per call, independent of launch
+geometry; the distribution is the reference's -- uniform over the items of a user that are not in
+``excluded_pairs``.  ``Sampler(seed=s)`` is reproducible.  ``Sampler()`` -- what the reference's scripts build, three
+of them for train / valid / test (scripts/neuralcf.py:27-47) -- takes a fresh stream per INSTANCE, as the reference's
+draws from Python's global ``random`` do: two default-constructed samplers never share their negatives (equal
+streams would leak the evaluation negatives into training).  The streams follow ``torch.initial_seed()``, so a
+script that calls ``torch.manual_seed`` first is still reproducible as a whole."""
 from __future__ import annotations
+
+import itertools
 
 import numpy as np
 import torch
 
 from .. import _lib
+
+_INSTANCES = itertools.count(1)   # process-wide: one stream per default-constructed Sampler
 
 
 def excluded_bitmap(num_user: int, num_item: int, excluded_pairs, device) -> torch.Tensor:
@@ -34,9 +41,12 @@ def excluded_bitmap(num_user: int, num_item: int, excluded_pairs, device) -> tor
 
 
 class Sampler:
-    def __init__(self, seed: int = 0):
+    def __init__(self, seed=None):
         self.negative_users = []
         self.negative_items = []
+        if seed is None:
+            # (initial_seed, instance number) -> a 64-bit stream id; the odd multipliers keep distinct pairs distinct
+            seed = (torch.initial_seed() * 0xD1342543DE82EF95 + next(_INSTANCES) * 0xA0761D6478BD642F) & 0xFFFFFFFFFFFFFFFF
         self._seed, self._calls = int(seed), 0
 
     def _draw(self, num_user, num_item, excluded_pairs, num_negatives, device):

@@ -91,19 +91,6 @@ int ctr_embed_fwd(const ctr_field_t* fields, int nfields, const float* x, int64_
 int ctr_embed_bwd(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx,
                   int64_t batch, const float* gout, int64_t ldo,
                   float* workspace, int64_t workspace_floats, void* stream);
-/* ctr_embed_bwd in two parts.  For tables much smaller than the batch the backward first sorts the samples by
- * row (counting sort) and then reduces runs of equal rows; the sort needs the ids only, so it can be enqueued
- * early -- on a side stream while the forward runs -- and the backward proper starts at the reduce:
- *   ctr_embed_bwd_presort  : the sort alone (no gradient pointers needed; ldo = leading dimension gout will have)
- *   ctr_embed_bwd_presorted: ctr_embed_bwd minus the sort, over what the former left in `workspace`
- * Same fields (gradient pointers aside), x, batch, ldo, workspace and workspace_floats in both calls; nothing else
- * may write the workspace in between.  Fields the sorted path does not take behave as in ctr_embed_bwd. */
-int ctr_embed_bwd_presort(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx, int64_t batch,
-                          int64_t ldo, float* workspace, int64_t workspace_floats, void* stream);
-int ctr_embed_bwd_presorted(const ctr_field_t* fields, int nfields, const float* x, int64_t ldx,
-                            int64_t batch, const float* gout, int64_t ldo,
-                            float* workspace, int64_t workspace_floats, void* stream);
-
 /* ------------------------------------------------------------------------
  * Matrix factorisation, fused (model/mf.py:23-26):
  *   prob[b] = sigmoid(sum_e U[u[b],e] * V[i[b],e])

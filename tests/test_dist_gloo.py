@@ -77,6 +77,32 @@ def _sharded_worker(rank, world, port, vocab, dim, out):
             raise AssertionError("out-of-range id was not reported")
         except IndexError:
             pass
+        # ... on EVERY rank, also when only one rank holds the bad id (the peers would otherwise walk into the next
+        # collective alone and hang until the timeout): rank 0 alone has it, both raise, the group stays usable
+        one = ids.clone()
+        if rank == 0:
+            one[2, 0] = -1
+        try:
+            emb(one)
+            raise AssertionError(f"rank {rank}: a peer's out-of-range id was not reported here")
+        except IndexError:
+            pass
+        assert torch.equal(emb(ids), full[ids])
+        # plans keyed by (anchor, other tensor): a persistent anchor with TEMPORARY partners (DIN's
+        # model(hist, pos_items) then model(hist, neg_items)) -- CPython gives a freed tensor's id to the next one of
+        # the same size and its version starts at 0 again, so identity + version alone would find the stale plan
+        hist = ids[:, :2].contiguous()
+        seen = set()
+        for shift in range(4):
+            target = (ids[:, 2] + shift) % vocab                    # a new temporary each round
+            seen.add(id(target))
+            both = torch.cat([hist.reshape(-1), target])
+            assert torch.equal(emb(both, plan_key=(hist, target)), full[both]), f"stale plan at shift {shift}"
+            del target, both
+        target = ids[:, 2].clone()
+        both = torch.cat([hist.reshape(-1), target])
+        p1 = ctr_dist.exchange_plan(both, emb, key=(hist, target))
+        assert ctr_dist.exchange_plan(both, emb, key=(hist, target)) is p1   # same live tensors: cached
         # empty batch on one rank must not deadlock the exchange
         empty = emb(torch.zeros((0,), dtype=torch.int64) if rank == 0 else ids[:2, 0])
         assert empty.shape[-1] == dim

@@ -88,3 +88,13 @@ def test_reference_import_lines_resolve_to_the_mirrors(tmp_path):
                          timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip() == "ok 14"
+
+
+def test_default_samplers_get_distinct_streams():
+    """``Sampler()`` x 3 (train / valid / test in the reference's scripts) must not share a stream; ``Sampler(seed=)``
+    stays reproducible"""
+    from deeplearningrecommendationsystem_amd.sampler import Sampler
+    seeds = {Sampler()._seed for _ in range(8)}
+    assert len(seeds) == 8
+    assert Sampler(seed=5)._seed == Sampler(seed=5)._seed == 5
+    assert all(0 <= s < 2 ** 64 for s in seeds)
