@@ -54,15 +54,31 @@ class KernelProfiler:
         self.records.append((label, nbytes, flops, start, end))
 
     def summary(self):
-        """{label: dict(calls, avg_us, bytes, flops)} -- call after a sync"""
+        """{label: dict(calls, total_us, avg_us, bytes, flops)} -- call after a sync.  ``bytes`` / ``flops`` are the
+        AVERAGE per call of what the calls under that label declared, ``avg_us`` the average duration: a label that
+        covers launches of different shapes (two stacks through ``mlp_fused_fwd``) then still gives a physically
+        possible rate, total work over total time (round 2 divided the first call's work by the average time of
+        all calls and printed a fraction above 1).  ``shapes`` counts the distinct (bytes, flops) pairs seen."""
         torch.cuda.synchronize()
+        return self.fold([(label, nbytes, flops, start.elapsed_time(end) * 1e3)
+                          for label, nbytes, flops, start, end in self.records])
+
+    @staticmethod
+    def fold(timed):
+        """``summary`` over (label, bytes, flops, microseconds) records"""
         out = {}
-        for label, nbytes, flops, start, end in self.records:
-            d = out.setdefault(label, dict(calls=0, total_us=0.0, bytes=nbytes, flops=flops))
+        for label, nbytes, flops, us in timed:
+            d = out.setdefault(label, dict(calls=0, total_us=0.0, total_bytes=0, total_flops=0, _shapes=set()))
             d["calls"] += 1
-            d["total_us"] += start.elapsed_time(end) * 1e3
+            d["total_us"] += us
+            d["total_bytes"] += nbytes
+            d["total_flops"] += flops
+            d["_shapes"].add((nbytes, flops))
         for d in out.values():
             d["avg_us"] = d["total_us"] / d["calls"]
+            d["bytes"] = d["total_bytes"] / d["calls"]
+            d["flops"] = d["total_flops"] / d["calls"]
+            d["shapes"] = len(d.pop("_shapes"))
         return out
 
 

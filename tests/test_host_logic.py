@@ -98,3 +98,29 @@ def test_default_samplers_get_distinct_streams():
     assert len(seeds) == 8
     assert Sampler(seed=5)._seed == Sampler(seed=5)._seed == 5
     assert all(0 <= s < 2 ** 64 for s in seeds)
+
+
+def test_kernel_profiler_mixed_shapes_and_roofline_bounds():
+    """a label covering two shapes must report total work over total time (round 2 printed a
+    fraction of 1.13), and a byte-dominant launch whose PMC traffic is far under its algorithmic bytes is priced
+    against L2, not called an HBM fraction"""
+    import importlib
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    from deeplearningrecommendationsystem_amd.ops import KernelProfiler
+    # small fast stack first, big slow stack second, same label
+    k = KernelProfiler.fold([("mlp", 1e6, 2e9, 20.0), ("mlp", 1e8, 2e11, 2000.0), ("x", 2e6, 0, 3.0)])
+    assert k["mlp"]["calls"] == 2 and k["mlp"]["shapes"] == 2
+    e = bench.roofline_entry("mlp", k["mlp"])
+    assert e["bound"] == "mfma" and abs(e["achieved"] - (2e9 + 2e11) / 2020e-6 / 1e12) < 1e-6 and e["frac"] < 1.0
+    # byte-dominant, no PMC evidence, long launch: hbm
+    rec = dict(avg_us=50.0, bytes=2e8, flops=0)
+    assert bench.roofline_entry("g", rec)["bound"] == "hbm"
+    # PMC says 20 % of the algorithmic bytes reached DRAM: l2, fraction against the L2 rate
+    t = {"hbm_bytes_raw": 3e7, "hbm_bytes_fetch_x2": 4e7}
+    e = bench.roofline_entry("g", rec, t)
+    assert e["bound"] == "l2" and e["peak"] == bench.L2_PEAK_GBS and abs(e["dram_gbs"] - 4e7 / 50e-6 / 1e9) < 1e-6
+    # a 3 us launch moving 2 MB: latency
+    assert bench.roofline_entry("x", k["x"])["bound"] == "latency"
