@@ -453,6 +453,44 @@ def adam_update(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tens
     p[sel] = p[sel] - (lr / bc1) * (m[sel] / (v[sel].sqrt() / bc2 ** 0.5 + eps))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# recommendation(): the reference's per-user ranking loops, restated.  Returns (ids (users, k), scores (users, n)).
+# ---------------------------------------------------------------------------------------------------------------
+def recommend_ids(model: str, p: Params, num_users: int, num_items: int):
+    """model/mf.py:28-35 (ranks the raw dot products, k = num_items) and model/neuralcf.py:61-72 (one forward per
+    user over every item, k = num_items)"""
+    if model == "mf":
+        scores = torch.matmul(p["user_embeddings.weight"][:num_users], p["item_embeddings.weight"][:num_items].T)
+    else:
+        items = torch.arange(num_items)
+        scores = torch.stack([FORWARDS[model](p, torch.full((num_items,), u), items).view(-1) for u in range(num_users)])
+    return torch.topk(scores, num_items, dim=1).indices, scores
+
+
+def recommend_frame(model: str, p: Params, num_users: int, frame: torch.Tensor, k: int):
+    """model/pnn.py:133-143, model/deepfm.py:85-95: the rows of the (pairs, 45) user_item frame that carry user u,
+    scored by one forward, ranked by position within those rows"""
+    ids, scores = [], []
+    for u in range(num_users):
+        rows = frame[frame[:, 0] == u]
+        s = FORWARDS[model](p, rows).view(-1)
+        scores.append(s)
+        ids.append(torch.topk(s, k).indices)
+    return torch.stack(ids), torch.stack(scores)
+
+
+def recommend_hist(model: str, p: Params, num_users: int, num_items: int, hist_list, k: int):
+    """model/din.py:55-66, model/dien.py:70-81: the user's whole history repeated against every item"""
+    ids, scores = [], []
+    targets = torch.arange(num_items)
+    for u in range(num_users):
+        hist = torch.tensor(hist_list[u]).repeat(num_items, 1)
+        s = FORWARDS[model](p, hist, targets).view(-1)
+        scores.append(s)
+        ids.append(torch.topk(s, k).indices)
+    return torch.stack(ids), torch.stack(scores)
+
+
 FORWARDS: Dict[str, Callable[..., torch.Tensor]] = {
     "mf": mf_forward, "neuralcf": neuralcf_forward, "ffm": ffm_forward, "pnn": pnn_forward,
     "deepcrossing": deepcrossing_forward, "deepfm": deepfm_forward, "din": din_forward,

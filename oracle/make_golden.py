@@ -121,6 +121,88 @@ def _cases():
     return c
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# recommendation(): the reference's own ranking loops (model/mf.py:28-35, model/neuralcf.py:61-72,
+# model/pnn.py:133-143, model/deepfm.py:85-95, model/din.py:55-66, model/dien.py:70-81) on small seeded models.
+# Stored: the state_dict, the call's arguments as arrays, the returned ids (``topk``) and the reference's scores of
+# every candidate (``scores``: what its topk ranked), so that a test can tell a wrong ranking from a tie.
+# ---------------------------------------------------------------------------------------------------------------
+def _user_item_frame(num_users, num_items, gen):
+    """the frame data/reader.py:104-112 builds: every (user, item) pair, user-major, with the 45 feature columns
+    (user features constant per user, item features constant per item)"""
+    import pandas as pd
+    u = synth.feature_batch(num_users, 943, 1682, gen)      # row r: the features of user r (cols 2:26)
+    it = synth.feature_batch(num_items, 943, 1682, gen)     # row r: the genre flags of item r (cols 26:45)
+    rows = np.zeros((num_users * num_items, 45), dtype=np.float32)
+    rows[:, 0] = np.repeat(np.arange(num_users), num_items)
+    rows[:, 1] = np.tile(np.arange(num_items), num_users)
+    rows[:, 2:26] = np.repeat(u[:, 2:26].numpy(), num_items, axis=0)
+    rows[:, 26:45] = np.tile(it[:, 26:45].numpy(), (num_users, 1))
+    cols = ["user_id", "item_id", "age", "F", "M"] + [f"occ{k}" for k in range(21)] + [f"genre{k}" for k in range(19)]
+    return pd.DataFrame(rows, columns=cols)
+
+
+def _rec_cases():
+    c = {}
+    c["rec_mf"] = ("mf", (12, 20, 8), "ids", dict(num_users=12, num_items=20), 0)
+    c["rec_neuralcf"] = ("neuralcf", (12, 20, 8, [16, 8, 4]), "ids", dict(num_users=12, num_items=20), 1)
+    c["rec_pnn"] = ("pnn", (8, [32, 16, 8]), "frame", dict(num_users=6, num_items=30, k=10), 2)
+    c["rec_deepfm"] = ("deepfm", (6, 30, [32, 16, 1], 8), "frame", dict(num_users=6, num_items=30, k=10), 3)
+    c["rec_din"] = ("din", (30, 8), "hist", dict(num_users=7, num_items=30, k=10), 4)
+    c["rec_dien"] = ("dien", (30, 8), "hist", dict(num_users=7, num_items=30, k=10), 5)
+    return c
+
+
+def make_rec_fixtures(out_dir, classes):
+    total = 0
+    for name, (key, args, kind, kw, seed) in sorted(_rec_cases().items()):
+        torch.manual_seed(seed)
+        model = classes[key](*args)
+        model.eval()
+        gen = synth.generator(2000 + seed)
+        arrays = {}
+        nu, ni = kw["num_users"], kw["num_items"]
+        with torch.no_grad():
+            if kind == "ids":
+                topk = model.recommendation(nu, ni)
+                if key == "mf":   # model/mf.py:31-33 ranks the raw dot products
+                    scores = torch.matmul(model.user_embeddings.weight[:nu], model.item_embeddings.weight[:ni].T)
+                else:
+                    scores = torch.stack([model(torch.full((ni,), u), torch.arange(ni)).view(-1) for u in range(nu)])
+            elif kind == "frame":
+                frame = _user_item_frame(nu, ni, gen)
+                topk = model.recommendation(nu, frame, kw["k"])
+                scores = torch.stack([model(torch.Tensor(frame[frame["user_id"] == u].values)).view(-1)
+                                      for u in range(nu)])
+                arrays["frame"] = frame.values.astype(np.float32)
+                arrays["k"] = np.int64(kw["k"])
+            else:
+                lengths = [3, 7, 12, 5, 7, 1, 12][:nu]          # ragged, un-truncated histories (scripts/din.py:99-101)
+                hist_list = [torch.randint(0, ni, (n,), generator=gen).tolist() for n in lengths]
+                hist_list[1][0] = 0                              # the padding id inside a history
+                topk = model.recommendation(nu, ni, hist_list, kw["k"])
+                scores = torch.stack([model(torch.tensor(hist_list[u]).repeat(ni, 1), torch.arange(ni)).view(-1)
+                                      for u in range(nu)])
+                pad = np.full((nu, max(lengths)), -1, dtype=np.int64)
+                for u, h in enumerate(hist_list):
+                    pad[u, :len(h)] = h
+                arrays["hist"] = pad
+                arrays["hist_len"] = np.asarray(lengths, dtype=np.int64)
+                arrays["k"] = np.int64(kw["k"])
+        arrays["topk"] = np.asarray(topk, dtype=np.int64)
+        arrays["scores"] = scores.numpy()
+        arrays["num_users"], arrays["num_items"] = np.int64(nu), np.int64(ni)
+        for pname, pt in model.state_dict().items():
+            arrays[f"param/{pname}"] = pt.detach().numpy()
+        meta = {"model": key, "args": list(args), "kind": kind, "seed": seed, "torch": torch.__version__}
+        arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        path = os.path.join(out_dir, name + ".npz")
+        np.savez_compressed(path, **arrays)
+        total += os.path.getsize(path)
+        print(f"{name:24s} topk {arrays['topk'].shape} {os.path.getsize(path) / 1024:.1f} KiB")
+    return total
+
+
 def main():
     out_dir = os.path.join(REPO, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
@@ -150,6 +232,7 @@ def main():
         np.savez_compressed(path, **arrays)
         total += os.path.getsize(path)
         print(f"{name:24s} loss={loss.item():.6f} {os.path.getsize(path) / 1024:.1f} KiB")
+    total += make_rec_fixtures(out_dir, classes)
     print(f"total {total / 1024:.1f} KiB")
 
 

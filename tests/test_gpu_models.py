@@ -336,6 +336,84 @@ def _sharded_ffm_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
+def _sharded_ffm_1e6_worker(rank, world, port, out):
+    """BASELINE configs[3] shape on two ranks: k = 32, 1e6-row id tables (HBM-resident), 16384 samples per rank,
+    against the CPU oracle of the UNSHARDED model on the global batch (trainer/trainer.py:30-38 semantics: the global
+    loss is the mean over both ranks' samples)"""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from deeplearningrecommendationsystem_amd import synth
+        from deeplearningrecommendationsystem_amd.dist import GradBucket
+        from deeplearningrecommendationsystem_amd.loss import BCELoss
+        from deeplearningrecommendationsystem_amd.model import FFM
+        from deeplearningrecommendationsystem_amd.model.ffm import SHARDED
+        nu = ni = 1_000_000
+        k, per_rank = 32, 16384
+        torch.manual_seed(3)
+        full = FFM(43, k, num_users=nu, num_items=ni)       # CPU: parameters for the oracle
+        with torch.no_grad():                                # xavier rows of a 1e6-row table are ~1e-3: scale them up
+            for name, p in full.named_parameters():
+                if name.split(".")[0] in SHARDED + ("user", "item"):
+                    p.mul_(300.0)
+        sd = {n: v.detach().clone() for n, v in full.state_dict().items()}
+        torch.manual_seed(4)
+        with torch.device(DEV):
+            shard = FFM(43, k, num_users=nu, num_items=ni, sharded=True)
+        for name, p in shard.named_parameters():
+            base = name.split(".")[0]
+            if base in SHARDED:
+                getattr(shard, base).load_full_table(sd[name].to(DEV))
+            else:
+                p.data.copy_(sd[name])
+        gen = synth.generator(9)
+        x = synth.feature_batch(world * per_rank, nu, ni, gen)
+        x[0, 0], x[1, 1], x[2, 0] = nu - 1, ni - 1, 0       # table edges
+        x[3:7, 0] = x[7, 0]                                  # duplicates inside a rank's batch
+        y = synth.labels(world * per_rank, True, gen)
+        prob_ref, loss_ref, grads_ref = orc.step("ffm", sd, [x], y)
+        assert float(prob_ref.std()) > 0.01, "degenerate case: the output must depend on the gathered rows"
+        mine = slice(rank * per_rank, (rank + 1) * per_rank)
+        prob = shard(x[mine].to(DEV))
+        BCELoss()(prob, y[mine].to(DEV)).backward()
+        GradBucket(shard.parameters()).all_reduce_mean()
+        torch.testing.assert_close(prob.detach().cpu(), prob_ref[mine], rtol=1e-5, atol=1e-6)
+        for name, p in shard.named_parameters():
+            want = grads_ref[name]
+            floor = 1e-6 + 1e-5 * float(want.abs().max())
+            if name.split(".")[0] in SHARDED:
+                want = want[rank::world]
+                got = p.grad[:want.shape[0]].cpu()
+            else:
+                got = p.grad.cpu()
+            torch.testing.assert_close(got, want, rtol=1e-4, atol=floor, msg=lambda m, n=name: f"{n}: {m}")
+        out.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        out.put((rank, traceback.format_exc()[-1500:]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_row_sharded_ffm_config3_shape_two_ranks_against_the_oracle():
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_ffm_1e6_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(500)
+    results = dict(out.get(timeout=5) for _ in procs)
+    assert results == {0: "ok", 1: "ok"}, results
+
+
 @pytest.mark.timeout(300)
 def test_row_sharded_ffm_two_ranks_match_the_unsharded_model():
     # BASELINE configs[3]: the field-aware id tables row-sharded, lookups by all-to-all
@@ -557,6 +635,29 @@ def test_script_counterparts_run_with_the_reference_import_lines(script, capsys,
 # ---------------------------------------------------------------------------
 # batched recommendation(): same ranking as the reference's per-user loop
 # ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", gu.rec_names())
+def test_recommendation_reproduces_the_reference_fixture(name):
+    """the ids the REFERENCE's recommendation() returned (tests/golden/rec_*.npz, oracle/make_golden.py: model/mf.py:28-35,
+    neuralcf.py:61-72, pnn.py:133-143, deepfm.py:85-95, din.py:55-66, dien.py:70-81) against the batched HIP
+    recommendation() on the same state_dict and arguments; a differing position must be a tie in the reference's scores"""
+    import pandas as pd
+    g = gu.load_rec(name)
+    meta = g["meta"]
+    module = _models()[meta["model"]](*meta["args"])
+    module.load_state_dict(g["params"], strict=True)
+    module = module.to(DEV).eval()
+    nu, ni = g["num_users"], g["num_items"]
+    if meta["kind"] == "ids":
+        got = module.recommendation(nu, ni)
+    elif meta["kind"] == "frame":
+        cols = ["user_id", "item_id"] + [f"f{c}" for c in range(43)]
+        got = module.recommendation(nu, pd.DataFrame(g["frame"], columns=cols), g["k"])
+    else:
+        got = module.recommendation(nu, ni, g["hist_list"], g["k"])
+    # fp32 scores differ from the reference's CPU sums in the last bits: near-ties (1e-5 relative) may swap
+    gu.assert_same_ranking(got, g["topk"], g["scores"], tol=1e-5)
+
+
 def _per_user_loop_feature(model, num_users, user_item, k):
     """the reference's recommendation() body (model/pnn.py:133-143), one forward per user"""
     rows = []

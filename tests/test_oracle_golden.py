@@ -147,3 +147,20 @@ def test_pnn_fields_oracle_reduces_to_the_pinned_six_field_oracle(name):
     same.update({k: k for k in pf if k.startswith(("product.", "dnn.", "output."))})
     for kf, k6 in same.items():
         torch.testing.assert_close(gradsf[kf], grads6[k6], rtol=1e-5, atol=1e-7, msg=lambda m, kf=kf: f"{kf}: {m}")
+
+
+@pytest.mark.parametrize("name", gu.rec_names())
+def test_oracle_recommendation_matches_the_reference(name):
+    """the reference's own recommendation() output (ids) and the scores it ranked, against the oracle's
+    restatement of the per-user loops on the fixture's state_dict"""
+    g = gu.load_rec(name)
+    model, nu, ni = g["meta"]["model"], g["num_users"], g["num_items"]
+    with torch.no_grad():
+        if g["meta"]["kind"] == "ids":
+            ids, scores = orc.recommend_ids(model, g["params"], nu, ni)
+        elif g["meta"]["kind"] == "frame":
+            ids, scores = orc.recommend_frame(model, g["params"], nu, torch.from_numpy(g["frame"]), g["k"])
+        else:
+            ids, scores = orc.recommend_hist(model, g["params"], nu, ni, g["hist_list"], g["k"])
+    torch.testing.assert_close(scores, torch.from_numpy(g["scores"]), rtol=1e-6, atol=1e-7)
+    gu.assert_same_ranking(ids.numpy(), g["topk"], g["scores"])
