@@ -15,10 +15,11 @@ import torch  # noqa: F401  (maps libamdhip64 first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTRHIP_LIB", os.path.join(_HERE, "libctrhip.so"))  # env override: A/B builds
-ABI_VERSION = 27
+ABI_VERSION = 28
 DIN_TRIPLE, DIN_PAIR, DIN_H = 0, 1, 2  # layouts of the DIN attention operand (include/ctrhip.h)
 
 CTR_MAX_FIELDS = 32
+CTR_NCF_PROJ_MAX_ROWS = 16384
 FIELD_ID_I64, FIELD_ID_F32, FIELD_BAG, FIELD_DENSE, FIELD_PROD_I64 = range(5)
 ACT_NONE, ACT_RELU, ACT_SIGMOID = range(3)
 
@@ -67,6 +68,28 @@ class MlpLayer(C.Structure):
     _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("y", C.c_void_p), ("ldy", C.c_int64),
                 ("gw", C.c_void_p), ("gb", C.c_void_p), ("n", C.c_int32), ("k", C.c_int32), ("act", C.c_int32),
                 ("reserved", C.c_int32)]
+
+
+class NcfProj(C.Structure):
+    """mirror of ``ctr_ncf_proj_t``"""
+    _fields_ = [("user_idx", C.c_void_p), ("user_stride", C.c_int64), ("item_idx", C.c_void_p), ("item_stride", C.c_int64),
+                ("batch", C.c_int64), ("num_users", C.c_int64), ("num_items", C.c_int64),
+                ("mlp_user", C.c_void_p), ("mlp_item", C.c_void_p), ("gmf_user", C.c_void_p), ("gmf_item", C.c_void_p),
+                ("mlp_dim", C.c_int32), ("mf_dim", C.c_int32), ("layers", MlpLayer * 4),
+                ("proj_w", C.c_void_p), ("ld_proj_w", C.c_int64), ("proj_b", C.c_void_p), ("proj_n", C.c_int32),
+                ("proj_k", C.c_int32), ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("head_act", C.c_int32),
+                ("prob", C.c_void_p), ("ldprob", C.c_int64), ("err_flag", C.c_void_p),
+                ("ptab", C.c_void_p), ("wfold", C.c_void_p), ("counts", C.c_void_p), ("ranks", C.c_void_p),
+                ("training", C.c_int32)]
+
+
+class NcfProjGrad(C.Structure):
+    """mirror of ``ctr_ncf_proj_grad_t``"""
+    _fields_ = [("gprob", C.c_void_p), ("ldgprob", C.c_int64), ("layers", MlpLayer * 4),
+                ("g_mlp_user", C.c_void_p), ("g_mlp_item", C.c_void_p), ("g_gmf_user", C.c_void_p), ("g_gmf_item", C.c_void_p),
+                ("g_proj_w", C.c_void_p), ("ld_g_proj_w", C.c_int64), ("g_proj_b", C.c_void_p), ("g_head_w", C.c_void_p),
+                ("g_head_b", C.c_void_p), ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
+                ("zero_buf", C.c_void_p), ("zero_floats", C.c_int64)]
 
 
 class AdamTensor(C.Structure):
@@ -138,6 +161,9 @@ SIGNATURES = {
     "ctr_embed_mlp_head_bwd": (_i, [C.POINTER(Field), _i, _l, C.POINTER(MlpLayer), _i, C.POINTER(MlpHeadGrad),
                                     C.POINTER(HeadFoldGrad), _p, _l, _p, _l, _p, _l, _p]),
     "ctr_mlp_head_bwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, C.POINTER(MlpHeadGrad), _p, _l, _p, _l, _p]),
+    "ctr_ncf_proj_workspace_floats": (_i, [_l, _l, _l, C.POINTER(C.c_int64)]),
+    "ctr_ncf_proj_fwd": (_i, [C.POINTER(NcfProj), _p]),
+    "ctr_ncf_proj_bwd": (_i, [C.POINTER(NcfProj), C.POINTER(NcfProjGrad), _p]),
     "ctr_mlp_bwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, _p, _l, _p, _l, _p, _l, _p]),
     "ctr_negative_sample": (_i, [_p, _l, _l, _l, _i, C.c_uint64, _p, _p, _p, _p]),
     "ctr_assemble_features": (_i, [_p, _p, _l, _p, _i, _l, _p, _i, _l, _p, _l, _p, _p]),

@@ -24,8 +24,6 @@
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 constexpr int kL = 4;
@@ -35,118 +33,15 @@ constexpr int kP = 64;        // head: extra (GMF) columns
 constexpr int kNL = 8;        // head: last activations
 constexpr int kHeadW = kP + kNL;
 
-constexpr int blocks(int units) { return (units + 15) / 16; }
-// float offset of layer l's operand-ordered weights: [out block][in block][lane][chunk]
-constexpr int wa_off(int l) {
-  int o = 0;
-  for (int i = 0; i < l; ++i) o += blocks(kN[i]) * blocks(kK[i]) * 256;
-  return o;
-}
-constexpr int kWFloats = wa_off(kL);   // 11008
-constexpr int b_off(int l) {
-  int o = 0;
-  for (int i = 0; i < l; ++i) o += blocks(kN[i]) * 16;
-  return o;
-}
-constexpr int kBFloats = b_off(kL);    // 128 (biases padded to whole blocks)
 
-struct Tower {
-  const float* w[kL];
-  const float* b[kL];
-  float* y[kL];
-  int64_t ldy[kL];
-};
+#include "mfma16_tower.inc"
+
 struct HeadFwd {
   const float* x; int64_t ldx;   // (m, >= 64) extra columns
   const float* w;                // 64 + 8 weights
   const float* c;                // one bias
   float* out; int64_t ldout; int act;
 };
-
-__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void stg4(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
-
-// forward A operands of every layer into LDS: s_w[wa_off(l) + ((b*J + j)*64 + lane)*4 + c] = W_l[16b + lane%16][16j + 4(lane/16) + c]
-// (rows past n: zero -- their outputs stay relu(0) = 0 and are never stored).  A dwordx4 of a weight row (inputs
-// 4t .. 4t+3) is one dwordx4 of the operand order (same block j, same lane, chunks 0..3): coalesced loads, all of a
-// thread's ~11 in flight before the first LDS store (one element at a time this was 43 dependent round trips).
-// Index math per layer with compile-time shapes, one `if` per bias / head-weight element: the prologue is executed by
-// every wave, and with three workgroups per CU its ~1600 instructions per wave were a third of a SIMD's issue time
-// (SQ counters: 1254 vector instructions per wave of which 229 matrix products).
-constexpr int fstage_per(int l) { return (16 * blocks(kN[l]) * (kK[l] / 4) + kThreads - 1) / kThreads; }
-constexpr int fstage_off(int l) {
-  int o = 0;
-  for (int i = 0; i < l; ++i) o += fstage_per(i);
-  return o;
-}
-constexpr int kFStagePer = fstage_off(kL);                   // 12
-template <int L>
-__device__ __forceinline__ void stage_forward_layer(const Tower& T, f32x4 (&v)[kFStagePer], int (&dst)[kFStagePer]) {
-  constexpr int K4 = kK[L] / 4, J = blocks(kK[L]), U = 16 * blocks(kN[L]) * K4;
-#pragma unroll
-  for (int i = 0; i < fstage_per(L); ++i) {
-    const int u = threadIdx.x + i * kThreads, at = fstage_off(L) + i;
-    v[at] = f32x4{0.f, 0.f, 0.f, 0.f};
-    dst[at] = -1;
-    if (u < U) {
-      const int unit = u / K4, t4 = u % K4;                  // row `unit` (padded to whole blocks), inputs 4 t4 ..
-      const int b = unit >> 4, j = t4 >> 2, qq = t4 & 3;
-      dst[at] = wa_off(L) + ((b * J + j) * 64 + qq * 16 + (unit & 15)) * 4;
-      if (unit < kN[L]) v[at] = ldg4(T.w[L] + unit * kK[L] + 4 * t4);
-    }
-  }
-}
-// in two halves (requests, then LDS stores) so that a kernel can put other requests between them
-__device__ __forceinline__ void stage_forward_load(const Tower& T, f32x4 (&v)[kFStagePer], int (&dst)[kFStagePer], float& bv) {
-  stage_forward_layer<0>(T, v, dst);
-  stage_forward_layer<1>(T, v, dst);
-  stage_forward_layer<2>(T, v, dst);
-  stage_forward_layer<3>(T, v, dst);
-  static_assert(kBFloats <= kThreads, "one bias element per thread");
-  bv = 0.0f;
-#pragma unroll
-  for (int l = 0; l < kL; ++l) {
-    const int i = (int)threadIdx.x - b_off(l);
-    if (i >= 0 && i < kN[l] && T.b[l]) bv = T.b[l][i];
-  }
-}
-__device__ __forceinline__ void stage_forward_store(float* s_w, float* s_b, const f32x4 (&v)[kFStagePer],
-                                                    const int (&dst)[kFStagePer], float bv) {
-#pragma unroll
-  for (int i = 0; i < kFStagePer; ++i)
-    if (dst[i] >= 0) *reinterpret_cast<f32x4*>(s_w + dst[i]) = v[i];
-  if (threadIdx.x < kBFloats) s_b[threadIdx.x] = bv;
-}
-
-template <int L, int NIN>   // one layer: NIN input blocks in registers -> blocks(kN[L]) output blocks
-__device__ __forceinline__ void layer_fwd(const float* s_w, const float* s_b, int lane, int q, const f32x4 (&in)[NIN],
-                                          f32x4 (&out)[blocks(kN[L])]) {
-  constexpr int B = blocks(kN[L]), J = blocks(kK[L]);
-  static_assert(J == NIN, "input blocks");
-#pragma unroll
-  for (int b = 0; b < B; ++b) out[b] = *reinterpret_cast<const f32x4*>(s_b + b_off(L) + 16 * b + 4 * q);
-  // (input block j, output block b) steps, B independent accumulator chains interleaved; the operand of step s+2 is
-  // requested while step s multiplies.  The compiler otherwise either hoists every weight read of the layer (344
-  // registers, one wave per SIMD) or, held to a register budget, reads each one right in front of its use.
-  constexpr int S = J * B;
-  const float* wbase = s_w + wa_off(L) + lane * 4;
-  auto wread = [&](int s2) { return *reinterpret_cast<const f32x4*>(wbase + (((s2 % B) * J + s2 / B) * 64) * 4); };
-  f32x4 w0 = wread(0), w1 = S > 1 ? wread(1) : w0;
-#pragma unroll
-  for (int s2 = 0; s2 < S; ++s2) {
-    const int j = s2 / B, b = s2 % B;
-    const f32x4 wa = w0;
-    w0 = w1;
-    if (s2 + 2 < S) w1 = wread(s2 + 2);
-    asm volatile("" ::: "memory");   // later weight reads stay behind this point
-#pragma unroll
-    for (int c = 0; c < 4; ++c) out[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c], in[j][c], out[b], 0, 0, 0);
-  }
-#pragma unroll
-  for (int b = 0; b < B; ++b)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) out[b][r] = fmaxf(out[b][r], 0.0f);
-}
 
 // The embedding stage in front of the tower (NeuralCF: x = [MLP_U[u] | MLP_I[i]], extra columns = GMF_U[u] * GMF_I[i],
 // reference model/neuralcf.py:37-47).  GATHER: the kernel reads the ids and the table rows itself (the tables of the
@@ -338,8 +233,6 @@ struct HeadBwd {
   int act;
 };
 
-constexpr int kTS = 20;                                   // row stride of a transposition tile (16-byte aligned rows)
-constexpr int kTile = 16 * kTS;
 constexpr int kStrip = 6 * kTile;                         // per wave: tiles A0 A1 | B0..B3 (layers alternate)
 constexpr int kBwdMain = kWFloats + kWaves * kStrip;      // floats: transposed weights, then the waves' strips
 constexpr int slab_w(int l) {                             // float offset of layer l's dW inside a slab
@@ -362,132 +255,6 @@ constexpr int kSmall = small_b(kL) + kHeadW + 1;          // 193
 constexpr int kSmallVecs = 13;                            // bias sums 4 + 2 + 1 + 1, head: 1 + 4 (each 4 per lane)
 constexpr int kCopy = kVecFloats + kSmall + 3;            // 11204 (a multiple of 4: every copy stays 16-byte aligned)
 constexpr int kBwdLds = 3 * kCopy > kBwdMain ? 3 * kCopy : kBwdMain;
-
-// transposed A operands: s_wt[wa_off(l) + ((j*B + b)*64 + lane)*4 + c] = W_l[16b + 4(lane/16) + c][16j + lane%16]
-// dwordx4 units a thread stages per layer (2048, 512, 128, 64 units over 256 threads), and where they start in its arrays
-constexpr int stage_per(int l) { return (16 * blocks(kN[l]) * (kK[l] / 4) + kThreads - 1) / kThreads; }
-constexpr int stage_off(int l) {
-  int o = 0;
-  for (int i = 0; i < l; ++i) o += stage_per(i);
-  return o;
-}
-constexpr int kStagePer = stage_off(kL);                  // 12
-template <int L>
-__device__ __forceinline__ void stage_layer_load(const Tower& T, f32x4 (&v)[kStagePer], int (&dst)[kStagePer]) {
-  constexpr int K4 = kK[L] / 4, B = blocks(kN[L]), U = 16 * B * K4;
-#pragma unroll
-  for (int i = 0; i < stage_per(L); ++i) {
-    const int u = threadIdx.x + i * kThreads, at = stage_off(L) + i;
-    v[at] = f32x4{0.f, 0.f, 0.f, 0.f};
-    dst[at] = -1;
-    if (u < U) {
-      const int unit = u / K4, t4 = u % K4;               // W_L[unit][4 t4 .. 4 t4 + 3]  (K4 is a power of two)
-      const int b = unit >> 4, qq = (unit >> 2) & 3, c = unit & 3, j = t4 >> 2, lo0 = (4 * t4) & 15;
-      dst[at] = wa_off(L) + ((j * B + b) * 64 + qq * 16 + lo0) * 4 + c;   // + 4 per consecutive input
-      if (unit < kN[L]) v[at] = ldg4(T.w[L] + unit * kK[L] + 4 * t4);
-    }
-  }
-}
-// in two halves: the requests go out first, the group operands' requests behind them, and the LDS stores then wait for
-// the weights alone (loads return in order: behind the 72 operand loads they waited for all of those as well)
-__device__ __forceinline__ void stage_transposed_load(const Tower& T, f32x4 (&v)[kStagePer], int (&dst)[kStagePer]) {
-  stage_layer_load<0>(T, v, dst);
-  stage_layer_load<1>(T, v, dst);
-  stage_layer_load<2>(T, v, dst);
-  stage_layer_load<3>(T, v, dst);
-}
-__device__ __forceinline__ void stage_transposed_store(float* s_wt, const f32x4 (&v)[kStagePer], const int (&dst)[kStagePer]) {
-#pragma unroll
-  for (int i = 0; i < kStagePer; ++i)
-    if (dst[i] >= 0) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) s_wt[dst[i] + 4 * e] = v[i][e];
-    }
-}
-
-// sum over the 16 lanes of a DPP row, result in every lane
-__device__ __forceinline__ float row_sum16(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));  // row_ror:4
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x122, 0xF, 0xF, true));  // row_ror:2
-  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x121, 0xF, 0xF, true));  // row_ror:1
-  return v;
-}
-
-__device__ __forceinline__ f32x4 relu_mask(const f32x4& g, const f32x4& y) {
-  f32x4 o;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = y[r] > 0.0f ? g[r] : 0.0f;
-  return o;
-}
-
-// Transposition of gradient blocks through the wave's LDS tiles, in two halves so that matrix-core work sits between
-// the stores and the loads.  sample-major block (lane (q, n): units 4q + r of sample n) -> unit-major (lane (q, u):
-// unit u, samples 4q + c).  The LDS pipe serves a wave's requests in order; the clobbers keep the compiler from
-// reordering them.
-template <int NB>
-__device__ __forceinline__ void tiles_put(float* tiles, int q, int lo, const f32x4 (&v)[NB]) {
-  asm volatile("" ::: "memory");
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) tiles[b * kTile + (4 * q + r) * kTS + lo] = v[b][r];
-  asm volatile("" ::: "memory");
-}
-template <int NB>
-__device__ __forceinline__ void tiles_get(const float* tiles, int q, int lo, f32x4 (&t)[NB]) {
-  asm volatile("" ::: "memory");
-#pragma unroll
-  for (int b = 0; b < NB; ++b) t[b] = *reinterpret_cast<const f32x4*>(tiles + b * kTile + lo * kTS + 4 * q);
-  asm volatile("" ::: "memory");
-}
-
-// dX^T of layer L: out block j = sum_b sum_c WT_L[j][b][lane][c] (x) gz[b][c]   (out in the layout of gz).
-// The weight vectors are read one step ahead over the whole layer; the first pair comes in (requested by dx_first
-// before the preceding dW products), so no LDS round trip is waited out in front of the chain.
-template <int L>
-__device__ __forceinline__ void dx_first(const float* s_wt, int lane, f32x4& w0, f32x4& w1) {
-  constexpr int B = blocks(kN[L]), JO = blocks(kK[L]);
-  const float* base = s_wt + wa_off(L) + lane * 4;
-  asm volatile("" ::: "memory");
-  w0 = *reinterpret_cast<const f32x4*>(base);
-  if (JO > 1) w1 = *reinterpret_cast<const f32x4*>(base + B * 256);
-  asm volatile("" ::: "memory");
-}
-template <int L, int NB, typename Sink>
-__device__ __forceinline__ void dx_layer(const float* s_wt, int lane, const f32x4 (&gz)[NB], f32x4 w0, f32x4 w1, Sink&& sink) {
-  constexpr int B = blocks(kN[L]), JO = blocks(kK[L]);
-  static_assert(B == NB, "gradient blocks");
-  const float* base = s_wt + wa_off(L) + lane * 4;
-  if constexpr (JO == 1) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    static_assert(B == 1, "single output block: single contraction block");
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[c], gz[0][c], acc, 0, 0, 0);
-    sink(0, acc, acc);
-  } else {
-#pragma unroll
-    for (int j = 0; j < JO; j += 2) {
-      f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
-#pragma unroll
-      for (int b = 0; b < B; ++b) {
-        const f32x4 wa = w0, wc = w1;
-        const int nj = b + 1 < B ? j : j + 2, nb = b + 1 < B ? b + 1 : 0;
-        if (nj < JO) {
-          w0 = *reinterpret_cast<const f32x4*>(base + (nj * B + nb) * 256);
-          w1 = *reinterpret_cast<const f32x4*>(base + ((nj + 1) * B + nb) * 256);
-        }
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c], gz[b][c], a0, 0, 0, 0);
-          a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[c], gz[b][c], a1, 0, 0, 0);
-        }
-      }
-      sink(j, a0, a1);
-    }
-  }
-}
 
 #ifdef CTR_STAMPS
 __device__ unsigned long long g_stamps[4 * 16];

@@ -22,6 +22,46 @@ FUSED_GATHER = os.environ.get("CTR_NCF_FUSED_GATHER", "1") != "0"
 REGATHER = os.environ.get("CTR_NCF_REGATHER", "1") != "0"
 
 
+# Vocabularies much smaller than the batch (BASELINE configs[1]: 943 + 1682 rows, batch 65536): the first tower layer
+# and its backward on the TABLE ROWS instead of the samples (csrc/ncf_proj.hip, ops.NcfProj).  CTR_NCF_PROJ=0 keeps the
+# per-sample kernels for A/B; they are also what every other shape runs (and the cross-check of this path in the tests).
+PROJECT_TABLES = os.environ.get("CTR_NCF_PROJ", "1") != "0"
+
+
+class _NeuralCFProjFunction(torch.autograd.Function):
+    """inputs as ``_NeuralCFFunction``; one ``ctr_ncf_proj_fwd`` forward, one ``ctr_ncf_proj_bwd`` backward"""
+
+    @staticmethod
+    def forward(ctx, user_idx, item_idx, err_flag, n_hidden, gmf_u, gmf_i, mlp_u, mlp_i, *dense):
+        hidden = [Layer(dense[2 * k], dense[2 * k + 1], ACT_RELU) for k in range(n_hidden)]
+        proj = (dense[2 * n_hidden], dense[2 * n_hidden + 1])
+        head = (dense[2 * n_hidden + 2], dense[2 * n_hidden + 3])
+        training = any(ctx.needs_input_grad[4:])
+        run = ops.NcfProj(user_idx, item_idx, (gmf_u, gmf_i, mlp_u, mlp_i), hidden, proj, head, err_flag, training)
+        prob = run.forward()
+        if prob is None:
+            raise _lib_error("ctr_ncf_proj_fwd refused a shape NcfProj.supported() accepted")
+        ctx.run = run if training else None
+        ctx.save_for_backward(gmf_u, gmf_i, mlp_u, mlp_i, *dense)
+        return prob
+
+    @staticmethod
+    def backward(ctx, gprob):
+        run, params = ctx.run, ctx.saved_tensors
+        if run is None:
+            raise RuntimeError("NeuralCF backward without a training forward")
+        ctx.run = None
+        zeros = ops.zero_grads(list(params), lazy=True)   # cleared by the backward's first launch
+        flat = zeros.pop("flat")
+        run.backward(gprob.contiguous(), zeros, flat)
+        return (None, None, None, None) + tuple(zeros[id(p)] for p in params)
+
+
+def _lib_error(msg):
+    from .._lib import CtrHipError
+    return CtrHipError(msg)
+
+
 class _NeuralCFFunction(torch.autograd.Function):
     """inputs: user_idx, item_idx, err_flag, n_hidden, then parameters in the
     order GMF_U, GMF_I, MLP_U, MLP_I, (W,b) x n_hidden, linear W,b, linear2 W,b.
@@ -178,9 +218,15 @@ class NeuralCF(CtrModule):
         dense = []
         for lin in list(self.dnn_network) + [self.linear, self.linear2]:
             dense += [lin.weight, lin.bias]
-        out = _NeuralCFFunction.apply(user_indices.contiguous(), item_indices.contiguous(), self._err_flag(w.device),
-                                      len(self.dnn_network), w, self.GMF_Embedding_Item.weight,
-                                      self.MLP_Embedding_User.weight, self.MLP_Embedding_Item.weight, *dense)
+        tables = (w, self.GMF_Embedding_Item.weight, self.MLP_Embedding_User.weight, self.MLP_Embedding_Item.weight)
+        hidden = [Layer(lin.weight, lin.bias, ACT_RELU) for lin in self.dnn_network]
+        fn = _NeuralCFFunction
+        if PROJECT_TABLES and user_indices.dim() == 1 and ops.NcfProj.supported(
+                tables, hidden, (self.linear.weight, self.linear.bias), user_indices.numel()) and not any(
+                getattr(t, "_ctr_sparse", None) is not None for t in tables):
+            fn = _NeuralCFProjFunction
+        out = fn.apply(user_indices.contiguous(), item_indices.contiguous(), self._err_flag(w.device),
+                       len(self.dnn_network), *tables, *dense)
         self._raise_if_bad_index()
         return out
 

@@ -619,6 +619,104 @@ def mlp_bwd(acts: Sequence[torch.Tensor], layers: Sequence[Layer], gy: torch.Ten
 
 
 # ---------------------------------------------------------------------------
+# NeuralCF with the first tower layer on the table rows (csrc/ncf_proj.hip)
+# ---------------------------------------------------------------------------
+class NcfProj:
+    """one forward of ``ctr_ncf_proj_fwd`` and what its backward needs.  ``tables`` = (gmf_u, gmf_i, mlp_u, mlp_i),
+    ``hidden`` = the four tower layers, ``proj`` = (w, b) of ``linear``, ``head`` = (w, b) of ``linear2``."""
+
+    def __init__(self, user_idx, item_idx, tables, hidden, proj, head, err_flag, training):
+        self.user_idx, self.item_idx = user_idx, item_idx
+        self.tables, self.hidden, self.proj, self.head = tables, hidden, proj, head
+        gmf_u, gmf_i, mlp_u, mlp_i = tables
+        dev = gmf_u.device
+        self.batch, self.nu, self.ni = user_idx.numel(), gmf_u.shape[0], gmf_i.shape[0]
+        m, rows = self.batch, self.nu + self.ni
+        self.ptab = torch.empty((rows, hidden[0].weight.shape[0]), dtype=torch.float32, device=dev)
+        self.wfold = torch.empty(76, dtype=torch.float32, device=dev)
+        self.ys = [torch.empty((m, layer.weight.shape[0]), dtype=torch.float32, device=dev) for layer in hidden[1:]]
+        self.prob = torch.empty((m, 1), dtype=torch.float32, device=dev)
+        self.counts = torch.empty(rows, dtype=torch.int32, device=dev) if training else None
+        self.ranks = torch.empty(2 * m, dtype=torch.int32, device=dev) if training else None
+        self.err_flag, self.training = err_flag, training
+
+    def _desc(self):
+        gmf_u, gmf_i, mlp_u, mlp_i = self.tables
+        d = _lib.NcfProj()
+        d.user_idx, d.user_stride = self.user_idx.data_ptr(), self.user_idx.stride(0) if self.user_idx.numel() > 1 else 1
+        d.item_idx, d.item_stride = self.item_idx.data_ptr(), self.item_idx.stride(0) if self.item_idx.numel() > 1 else 1
+        d.batch, d.num_users, d.num_items = self.batch, self.nu, self.ni
+        d.mlp_user, d.mlp_item, d.gmf_user, d.gmf_item = (t.data_ptr() for t in (mlp_u, mlp_i, gmf_u, gmf_i))
+        d.mlp_dim, d.mf_dim = mlp_u.shape[1], gmf_u.shape[1]
+        for k, layer in enumerate(self.hidden):
+            e = d.layers[k]
+            e.w, e.b, e.n, e.k, e.act = layer.weight.data_ptr(), _lib.ptr(layer.bias), layer.weight.shape[0], layer.weight.shape[1], layer.act
+            if k:
+                e.y, e.ldy = self.ys[k - 1].data_ptr(), _ld(self.ys[k - 1])
+        pw, pb = self.proj
+        hw, hb = self.head
+        d.proj_w, d.ld_proj_w, d.proj_b, d.proj_n, d.proj_k = pw.data_ptr(), _ld(pw), _lib.ptr(pb), pw.shape[0], pw.shape[1]
+        d.head_w, d.head_b, d.head_act = hw.data_ptr(), _lib.ptr(hb), ACT_SIGMOID
+        d.prob, d.ldprob, d.err_flag = self.prob.data_ptr(), 1, _lib.ptr(self.err_flag)
+        d.ptab, d.wfold, d.counts, d.ranks = self.ptab.data_ptr(), self.wfold.data_ptr(), _lib.ptr(self.counts), _lib.ptr(self.ranks)
+        d.training = 1 if self.training else 0
+        return d
+
+    @staticmethod
+    def supported(tables, hidden, proj, batch) -> bool:
+        gmf_u, gmf_i, mlp_u, mlp_i = tables
+        rows = gmf_u.shape[0] + gmf_i.shape[0]
+        dims = [tuple(layer.weight.shape) for layer in hidden]
+        return (dims == [(64, 128), (32, 64), (16, 32), (8, 16)] and gmf_u.shape[1] == 64 and mlp_u.shape[1] == 64 and
+                tuple(proj[0].shape) == (64, 8) and all(layer.bias is not None for layer in hidden) and
+                rows <= _lib.CTR_NCF_PROJ_MAX_ROWS and batch >= 4096 and batch >= 4 * rows and 2 * batch < 2 ** 31)
+
+    def _meta(self, backward):
+        m, rows = self.batch, self.nu + self.ni
+        tower = 64 * 32 + 32 * 16 + 16 * 8
+        if not backward:
+            # ids, four 256-byte rows (cache-resident), saved activations + prob written; tower + head + row products
+            return lambda: (m * (16 + 4 * 256 + 4 * (32 + 16 + 8) + 4 + 8), 2 * m * (tower + 72 + 64) + 2 * rows * 64 * 64)
+        # activations + rows read again, one gz0 row written twice and read once per table, per-row products
+        return lambda: (m * (16 + 2 * 256 + 4 * (32 + 16 + 8) + 12 + 4 * (2 * 64 + 8) + 4 * 256),
+                        4 * m * tower + 2 * m * 72 + 2 * m * 2 * 64 + 3 * 2 * rows * 64 * 64)
+
+    def forward(self) -> torch.Tensor:
+        d = self._desc()
+        rc = _timed("ncf_proj_fwd", self._meta(False), _lib.load().ctr_ncf_proj_fwd, C.byref(d), _lib.stream_ptr())
+        if rc in _REFUSED:
+            if _profiler is not None and _profiler.records and _profiler.records[-1][0] == "ncf_proj_fwd":
+                _profiler.records.pop()
+            return None
+        _lib.check(rc, "ctr_ncf_proj_fwd")
+        return self.prob
+
+    def backward(self, gprob: torch.Tensor, grads: dict, zero: Optional[torch.Tensor]) -> None:
+        """``grads[id(param)]``: where each parameter's gradient accumulates; ``zero``: the flat buffer behind them,
+        cleared by the call's first launch"""
+        gmf_u, gmf_i, mlp_u, mlp_i = self.tables
+        d = self._desc()
+        g = _lib.NcfProjGrad()
+        gprob = gprob.reshape(-1)
+        g.gprob, g.ldgprob = gprob.data_ptr(), gprob.stride(0) if gprob.numel() > 1 else 1
+        for k, layer in enumerate(self.hidden):
+            g.layers[k].gw, g.layers[k].gb = grads[id(layer.weight)].data_ptr(), grads[id(layer.bias)].data_ptr()
+        g.g_mlp_user, g.g_mlp_item, g.g_gmf_user, g.g_gmf_item = (grads[id(t)].data_ptr() for t in (mlp_u, mlp_i, gmf_u, gmf_i))
+        pw, pb = self.proj
+        hw, hb = self.head
+        g.g_proj_w, g.ld_g_proj_w, g.g_proj_b = grads[id(pw)].data_ptr(), _ld(grads[id(pw)]), _lib.ptr(grads.get(id(pb)))
+        g.g_head_w, g.g_head_b = grads[id(hw)].data_ptr(), _lib.ptr(grads.get(id(hb)))
+        need = C.c_int64(0)
+        _lib.check(_lib.load().ctr_ncf_proj_workspace_floats(self.batch, self.nu, self.ni, C.byref(need)), "workspace")
+        ws = _scratch(gmf_u.device) if need.value <= SCRATCH_FLOATS else torch.empty(need.value, dtype=torch.float32,
+                                                                                      device=gmf_u.device)
+        g.workspace, g.workspace_floats = ws.data_ptr(), ws.numel()
+        g.zero_buf, g.zero_floats = _lib.ptr(zero), zero.numel() if zero is not None else 0
+        rc = _timed("ncf_proj_bwd", self._meta(True), _lib.load().ctr_ncf_proj_bwd, C.byref(d), C.byref(g), _lib.stream_ptr())
+        _lib.check(rc, "ctr_ncf_proj_bwd")
+
+
+# ---------------------------------------------------------------------------
 # feature interactions
 # ---------------------------------------------------------------------------
 USER_COL, ITEM_COL, DENSE_COL0, NUM_DENSE = 0, 1, 2, 43  # the (B,45) layout of data/reader.py:98-112

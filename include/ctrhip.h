@@ -432,6 +432,51 @@ int ctr_embed_mlp_head_bwd(const ctr_field_t* fields, int nfields, int64_t batch
                            int nlayers, const ctr_mlp_head_grad_t* hg, const ctr_head_fold_grad_t* fold /*nullable*/,
                            float* gx, int64_t ldgx, float* workspace, int64_t workspace_floats,
                            float* zero_buf /*nullable*/, int64_t zero_floats, void* stream);
+/* ------------------------------------------------------------------------
+ * NeuralCF (model/neuralcf.py:33-59) when the vocabularies are much smaller than the batch: the first tower layer and
+ * its whole backward are moved from the samples to the table rows.  Linear(cat(MLP_U[u], MLP_I[i])) ==
+ * (MLP_U W0a^T)[u] + (MLP_I W0b^T + b0)[i]: two products over num_users + num_items rows instead of one over the
+ * batch; backward: segment sums S_U / S_I of ONE 64-float row per sample, then dMLP = S W0half, dW0half = S^T MLP,
+ * db0 = colsum S_U; the GMF tables' gradients and the head's GMF weights from T_U[u] = sum_b gz_b GMF_I[i_b]
+ * likewise (csrc/ncf_proj.hip has the derivation).  Same function, same gradients as the per-sample path
+ * (ctr_embed_mlp_head_fwd / _bwd) up to fp32 summation order.
+ *
+ * Pattern (anything else: CTR_ELIMIT, nothing enqueued -- use the per-sample entry points): mlp_dim == mf_dim == 64,
+ * layers = {128->64, 64->32, 32->16, 16->8} all ReLU with biases, proj (`linear`) 8 -> 64, head (`linear2`) on
+ * [gmf | linear(h)] (128 weights), num_users + num_items <= CTR_NCF_PROJ_MAX_ROWS, 16-byte aligned tables.
+ * layers[0].y is not used (the first layer's output never exists per sample); layers[1..3].y are the saved
+ * activations (m, 32), (m, 16), (m, 8) the forward writes and the backward reads.
+ * Caller-owned buffers the forward fills for the backward: ptab (num_users + num_items, 64), wfold (76 floats),
+ * and with training != 0: counts (num_users + num_items int32), ranks (2 * batch int32).  Parameters must not
+ * change between the forward and the backward (the backward re-reads tables and ptab). */
+#define CTR_NCF_PROJ_MAX_ROWS 16384
+typedef struct ctr_ncf_proj {
+  const int64_t* user_idx; int64_t user_stride;   /* ids of the batch, element strides */
+  const int64_t* item_idx; int64_t item_stride;
+  int64_t batch, num_users, num_items;
+  const float* mlp_user; const float* mlp_item;   /* (num, mlp_dim) MLP_Embedding_User / _Item */
+  const float* gmf_user; const float* gmf_item;   /* (num, mf_dim)  GMF_Embedding_User / _Item */
+  int32_t mlp_dim, mf_dim;
+  ctr_mlp_layer_t layers[4];                      /* dnn_network (gw / gb unused here) */
+  const float* proj_w; int64_t ld_proj_w; const float* proj_b; int32_t proj_n, proj_k;   /* `linear` (proj_n, proj_k) */
+  const float* head_w; const float* head_b; int32_t head_act;                            /* `linear2` (1, 2 mf_dim) */
+  float* prob; int64_t ldprob;                    /* (batch) output */
+  int32_t* err_flag;                              /* nullable */
+  float* ptab; float* wfold; int32_t* counts; int32_t* ranks;
+  int32_t training;
+} ctr_ncf_proj_t;
+typedef struct ctr_ncf_proj_grad {
+  const float* gprob; int64_t ldgprob;
+  ctr_mlp_layer_t layers[4];                      /* gw / gb of dnn_network (+=); other members unused */
+  float* g_mlp_user; float* g_mlp_item; float* g_gmf_user; float* g_gmf_item;   /* dense table gradients (+=) */
+  float* g_proj_w; int64_t ld_g_proj_w; float* g_proj_b; float* g_head_w; float* g_head_b;   /* (+=) */
+  float* workspace; int64_t workspace_floats;     /* >= ctr_ncf_proj_workspace_floats(batch, users, items) */
+  float* zero_buf; int64_t zero_floats;           /* nullable: cleared by the call's first launch (see ctr_embed_mlp_head_bwd) */
+} ctr_ncf_proj_grad_t;
+int ctr_ncf_proj_workspace_floats(int64_t batch, int64_t num_users, int64_t num_items, int64_t* floats /*host, out*/);
+int ctr_ncf_proj_fwd(const ctr_ncf_proj_t* d, void* stream);
+int ctr_ncf_proj_bwd(const ctr_ncf_proj_t* d, const ctr_ncf_proj_grad_t* g, void* stream);
+
 /* gy: gradient of the LAST layer's output; gx (nullable): gradient of x.  workspace is
  * required: (number of workgroups <= 256) * sum_i (n_i*k_i + n_i) floats. */
 int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* layers, int nlayers,

@@ -57,6 +57,21 @@ def test_field_struct_matches_header_size(lib):
     assert ctypes.sizeof(lib.HeadFold) == 72
     # 9 pointers / int64 + 4 int32 = 88 bytes, as ctr_head_fold_grad_t
     assert ctypes.sizeof(lib.HeadFoldGrad) == 88
+    # ctr_ncf_proj_t / ctr_ncf_proj_grad_t: the library reports its own sizeof through an empty-batch refusal-free
+    # probe is not possible without a GPU; the sizes below are the header's (11 x 8 + 8 + 4 x 64 + 3 x 8 + 8 + 2 x 8 +
+    # 8 + 2 x 8 + 8 + 4 x 8 + 8 = 480; 2 x 8 + 4 x 64 + 13 x 8 = 376) and are asserted against a compiled probe
+    assert ctypes.sizeof(lib.NcfProj) == _c_sizeof("ctr_ncf_proj_t")
+    assert ctypes.sizeof(lib.NcfProjGrad) == _c_sizeof("ctr_ncf_proj_grad_t")
+
+
+def _c_sizeof(type_name):
+    """sizeof(type) as a C compiler sees include/ctrhip.h"""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "probe.c"), os.path.join(d, "probe")
+        open(src, "w").write(f'#include <stdio.h>\n#include "ctrhip.h"\nint main(void) {{ printf("%zu", sizeof({type_name})); return 0; }}\n')
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
+        return int(subprocess.run([exe], capture_output=True, text=True, check=True).stdout)
 
 
 def test_strerror(lib):
@@ -106,6 +121,10 @@ def _parse_header_prototypes():
                 a = a.strip()
                 if "ctr_field_t" in a:
                     kinds.append("field*")
+                elif "ctr_ncf_proj_grad_t" in a:
+                    kinds.append("ncfprojgrad*")
+                elif "ctr_ncf_proj_t" in a:
+                    kinds.append("ncfproj*")
                 elif "ctr_mlp_layer_t" in a:
                     kinds.append("mlp*")
                 elif "ctr_mlp_head_grad_t" in a:
@@ -157,6 +176,10 @@ def test_ctypes_signatures_match_header_prototypes(lib):
                 got.append("field*")
             elif a is ctypes.POINTER(lib.MlpLayer):
                 got.append("mlp*")
+            elif a is ctypes.POINTER(lib.NcfProj):
+                got.append("ncfproj*")
+            elif a is ctypes.POINTER(lib.NcfProjGrad):
+                got.append("ncfprojgrad*")
             elif a is ctypes.POINTER(lib.MlpHead):
                 got.append("head*")
             elif a is ctypes.POINTER(lib.MlpHeadGrad):

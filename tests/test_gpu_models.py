@@ -454,6 +454,89 @@ def test_row_sharded_item_table_two_ranks_match_the_unsharded_model(kind):
     assert results == {0: "ok", 1: "ok"}, results
 
 
+# ---------------------------------------------------------------------------
+# NeuralCF with the first tower layer on the table rows (csrc/ncf_proj.hip): taken when the vocabularies are much
+# smaller than the batch (BASELINE configs[1]); the per-sample kernels are its independent cross-check
+# ---------------------------------------------------------------------------
+def _ncf(nu, ni, seed=0):
+    from deeplearningrecommendationsystem_amd.model import NeuralCF
+    torch.manual_seed(seed)
+    return NeuralCF(nu, ni, 64, [128, 64, 32, 16, 8])
+
+
+def _ncf_step(module, u, i, y, project):
+    from deeplearningrecommendationsystem_amd.model import neuralcf as ncf_mod
+    from deeplearningrecommendationsystem_amd import ops
+    old = ncf_mod.PROJECT_TABLES
+    ncf_mod.PROJECT_TABLES = project
+    calls = []
+    real = ops.NcfProj.forward
+    ops.NcfProj.forward = lambda self: (calls.append(1), real(self))[1]
+    try:
+        out = _run(module, [u, i], y)
+    finally:
+        ncf_mod.PROJECT_TABLES = old
+        ops.NcfProj.forward = real
+    assert bool(calls) == bool(project), "the path under test was not the one that ran"
+    return out
+
+
+@pytest.mark.parametrize("nu,ni,batch,dist", [(943, 1682, 16384, "uniform"), (943, 1682, 65536 + 37, "uniform"),
+                                              (943, 1682, 20000, "zipf"), (5, 7, 4099, "uniform"),
+                                              (3000, 5000, 40000, "uniform")])
+def test_neuralcf_table_row_path_against_oracle_and_per_sample_path(nu, ni, batch, dist):
+    """forward, BCELoss, backward through ctr_ncf_proj_fwd / _bwd against the CPU oracle (prob / loss 1e-5, gradients at
+    the repo's tolerance) and against the per-sample kernels: ragged batches, a few huge rows (5 x 7 vocabulary),
+    Zipf ids (hot rows shared by many waves of the segment sum), vocabularies that are not multiples of 16"""
+    from deeplearningrecommendationsystem_amd import synth
+    module = _ncf(nu, ni, 11)
+    gen = synth.generator(batch)
+    if dist == "zipf":
+        u = (float(nu) ** torch.rand(batch, generator=gen, dtype=torch.float64) - 1.0).long().clamp_(0, nu - 1)
+        i = (float(ni) ** torch.rand(batch, generator=gen, dtype=torch.float64) - 1.0).long().clamp_(0, ni - 1)
+    else:
+        u, i = synth.id_batch(batch, nu, ni, gen)
+    u[0], i[0], u[1], i[1] = 0, 0, nu - 1, ni - 1
+    y = synth.labels(batch, True, gen)
+    params = {k: v.detach().clone() for k, v in module.state_dict().items()}
+    prob_ref, loss_ref, grads_ref = orc.step("neuralcf", params, [u, i], y)
+    module = module.to(DEV)
+    prob, loss, grads = _ncf_step(module, u, i, y, True)
+    torch.testing.assert_close(prob, prob_ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(loss, loss_ref, rtol=1e-5, atol=1e-6)
+    _check_grads(grads, grads_ref)
+    prob2, loss2, grads2 = _ncf_step(module, u, i, y, False)
+    torch.testing.assert_close(prob, prob2, rtol=1e-5, atol=1e-6)
+    _check_grads(grads, grads2)
+
+
+def test_neuralcf_table_row_path_bad_ids_and_inference():
+    """an id outside its table reads row 0 and raises the flag in the forward (nn.Embedding would raise IndexError:
+    the gradients of such a step are not defined, they only have to stay finite and leave every row of the bad id's
+    table alone that no good sample touched); under no_grad the forward keeps no counters and gives the same values"""
+    from deeplearningrecommendationsystem_amd import synth
+    nu, ni, batch = 50, 70, 8192
+    module = _ncf(nu, ni, 3).to(DEV)
+    gen = synth.generator(4)
+    u, i = synth.id_batch(batch, nu, ni, gen)
+    u[u == 7] = 8                      # no good sample touches user row 7
+    y = synth.labels(batch, True, gen)
+    ub, ib = u.clone(), i.clone()
+    ub[(torch.arange(batch) % 97) == 5] = nu + 3
+    ib[11] = -1
+    module.check_index = False
+    prob, loss, grads = _ncf_step(module, ub, ib, y, True)
+    with pytest.raises(IndexError):
+        module.check_bad_index()
+    assert all(bool(torch.isfinite(g).all()) for g in grads.values()) and bool(torch.isfinite(prob).all())
+    assert float(grads["MLP_Embedding_User.weight"][7].abs().sum()) == 0.0
+    assert float(grads["GMF_Embedding_User.weight"][7].abs().sum()) == 0.0
+    with torch.no_grad():
+        p_eval = module(u.to(DEV), i.to(DEV))
+    p_train = module(u.to(DEV), i.to(DEV))
+    torch.testing.assert_close(p_eval, p_train.detach(), rtol=0, atol=0)
+
+
 def test_neuralcf_recommendation_over_the_whole_grid_matches_the_per_user_loop():
     # SURVEY 8(f) rank 2: the reference ranks user by user (model/neuralcf.py:61-72); the mirror scores
     # the user x item grid in a few launches -- same ranking

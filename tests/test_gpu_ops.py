@@ -1049,20 +1049,13 @@ def test_gru_with_the_input_projection_inside_matches_torch_gru(ops, batch, leng
     for got, want in ((gw_ih, gru.weight_ih_l0), (gw_hh, gru.weight_hh_l0), (gb_ih, gru.bias_ih_l0), (gb_hh, gru.bias_hh_l0)):
         torch.testing.assert_close(got.cpu(), want.grad, rtol=1e-4, atol=1e-4 * max(1.0, (batch * length) ** 0.5 / 30))
     if batch % 4 == 0:
-        # rows that are not 16-byte aligned (a column slice of a 17-wide buffer) take the DPP-row kernels
+        # rows that are not 16-byte aligned (a column slice of a 17-wide buffer) are refused with nothing enqueued:
+        # the caller then forms gi with ctr_linear_fwd and runs ctr_gru_fwd / ctr_gru_bwd (model/dien.py does)
         wide = torch.zeros(batch * length, 17, device=DEV)
         wide[:, 1:] = xd
-        xs = wide[:, 1:]
         hbuf2 = torch.full((batch * (length + 1), dim), float("nan"), device=DEV)
-        assert ops.gru_fused_fwd(xs, w_ih, b_ih, w_hh, b_hh, batch, length, dim, hbuf2, None)
-        torch.testing.assert_close(hbuf2, hbuf, rtol=1e-5, atol=1e-5)
-        gxw = torch.full((batch * length, 17), float("nan"), device=DEV)
-        g2 = [torch.zeros_like(t) for t in (w_ih, b_ih, w_hh, b_hh)]
-        ops.gru_fused_bwd(xs, w_ih, b_ih, w_hh, b_hh, hbuf2, batch, length, dim, glast.to(DEV), gxw[:, 1:], g2[0], g2[1],
-                          g2[2], g2[3])
-        torch.testing.assert_close(gxw[:, 1:], gx, rtol=1e-4, atol=1e-5)
-        for got, want in zip(g2, (gw_ih, gb_ih, gw_hh, gb_hh)):
-            torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4 * max(1.0, (batch * length) ** 0.5 / 30))
+        assert not ops.gru_fused_fwd(wide[:, 1:], w_ih, b_ih, w_hh, b_hh, batch, length, dim, hbuf2, None)
+        assert bool(torch.isnan(hbuf2).all())
     # other widths are refused with nothing enqueued
     assert not ops.gru_fused_fwd(torch.zeros(8, 8, device=DEV), torch.zeros(24, 8, device=DEV), torch.zeros(24, device=DEV),
                                  torch.zeros(24, 8, device=DEV), torch.zeros(24, device=DEV), 4, 2, 8,
