@@ -26,6 +26,8 @@
 // (tower dW partials, head fold chain rule) -> ncfp_segsum -> ncfp_finish (the table-row products).
 #include "ctr_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -40,6 +42,14 @@ constexpr int kNL = 8;                         // head: last activations
 constexpr int kHeadW = kP + kNL;
 
 #include "mfma16_tower.inc"
+
+#ifdef CTR_STAMPS
+// dev/ncfp_stamps.py: cycle stamps of wave 0 of workgroup 7 (a build of its own: the product has no stamp instruction)
+__device__ unsigned long long g_stamps[2][64];
+#define STAMP(k, i) do { const int at_ = (i); if (blockIdx.x == 7 && threadIdx.x == 0 && at_ < 64) g_stamps[k][at_] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(k, i) do {} while (0)
+#endif
 
 struct Ids {
   const int64_t* uidx; int64_t ustride;
@@ -69,24 +79,28 @@ ncfp_prep_kernel(const Prep A) {
       A.counts[i] = 0;
   }
   if (blockIdx.x == gridDim.x - 1) {
-    // the folded head: thread t < 64 copies u[t]; 64..71 column t - 64 of W^T u[64:]; 72 the folded bias
+    // the folded head (ctr_fold_head_fwd's map): wfold[t < 64] = u[t]; wfold[64 + c] = sum_i W[i][c] u[64 + i] (column c
+    // by the 32 threads t % 8 == c, two terms each, summed through LDS); wfold[72] = b . u[64:] + b2
+    __shared__ float s_f[kThreads];
     const int t = threadIdx.x;
-    if (t < kP) {
-      A.wfold[t] = A.fold_u[t];
-    } else if (t < kHeadW) {
-      const float* wc = A.fold_w + (t - kP);
-      const float* u = A.fold_u + kP;
-      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int i0 = 0; i0 < 64; i0 += 8) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(wc[(int64_t)(i0 + e) * A.fold_ldw], u[i0 + e], acc[e]);
-      }
-      A.wfold[t] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-    } else if (t == kHeadW) {
-      const float* u = A.fold_u + kP;
+    const float* u = A.fold_u + kP;
+    if (t < kP) A.wfold[t] = A.fold_u[t];
+    {
+      const int c = t & 7, i = t >> 3;                 // i in 0..31: terms i and i + 32
+      s_f[t] = fmaf(A.fold_w[(int64_t)i * A.fold_ldw + c], u[i], A.fold_w[(int64_t)(i + 32) * A.fold_ldw + c] * u[i + 32]);
+    }
+    __syncthreads();
+    if (t < kNL) {
+      float acc = 0.0f;
+      for (int i = 0; i < 32; ++i) acc += s_f[8 * i + t];
+      A.wfold[kP + t] = acc;
+    }
+    __syncthreads();
+    if (t < 64) s_f[t] = A.fold_b ? A.fold_b[t] * u[t] : 0.0f;
+    __syncthreads();
+    if (t == 0) {
       float acc = A.fold_b2 ? A.fold_b2[0] : 0.0f;
-      if (A.fold_b)
-        for (int i = 0; i < 64; ++i) acc = fmaf(A.fold_b[i], u[i], acc);
+      for (int i = 0; i < 64; ++i) acc += s_f[i];
       A.wfold[kHeadW] = acc;
     }
   }
@@ -131,59 +145,105 @@ struct Fwd {
   float* out; int64_t ldout; int act;
   int32_t* err_flag;
   int32_t* counts;                             // nullable (inference): per-row sample counters, users then items
-  int32_t* ranks;                              // (2, m): rank of a sample inside its user row / item row (-1: bad id)
+  int32_t* ranks;                              // (m + 1, 2): rank of a sample inside its user row / item row (-1: bad id)
 };
 
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 4)))
+// How the loops of this file are written (what the first version got wrong, found with cycle stamps, an ablation and
+// the TA / TCP counters: dev/r03_ablate.sh, dev/ncfp_stamps.py, profiles/r03_ncfp_*):
+//  * hipcc puts a `s_waitcnt vmcnt(0)` INSIDE every conditional block that consumes a load (`live ? a[i] + b[i] : 0`
+//    becomes a branch around two loads, their wait and the add): a fetch written that way is a chain of round trips.
+//    Every load here is unconditional (rows past the batch are clamped), every store too (lanes without a sample write
+//    to a spare row every per-sample buffer has), so the compiler can count them.
+//  * loading a gathered row straight into matrix-core operand layout -- lane (q, n) takes 16 bytes at column 16j + 4q
+//    of sample n's row -- makes NEIGHBOURING lanes read DIFFERENT rows: 64 separate 16-byte requests per instruction
+//    (TCP_TOTAL_CACHE_ACCESSES = 57 per vector-memory instruction, the texture addresser busy 75 % of the kernel).  The
+//    rows are therefore fetched COALESCED -- sixteen lanes per 256-byte row, four rows per instruction -- by LDS-DMA
+//    (global_load_lds_dwordx4: per-lane source address, wave-contiguous LDS image) into a wave-private stage, and read
+//    back in operand layout with ds_read_b128; the source chunk a lane fetches is XOR-swizzled with its row so that the
+//    sixteen rows a quarter-wave reads at one column land on sixteen different bank groups.
+//  * the two dependent stages of a gather -- ids, then the rows they name -- are split over iterations: group g waits
+//    once, reads its staged rows into registers, requests the rows of the next group (their ids arrived with that wait)
+//    and the ids of the one after, and only then computes.
+//
+// LDS-DMA and its waits are written by hand (the compiler cannot see which bytes an LDS-DMA writes and would wait for
+// every load in front of every LDS read).  Vector-memory operations retire in issue order; per group a wave issues
+//   [rank atomics: training] [kDma row fetches] [2 id loads] [kStores stores]
+// so `vmcnt(kStores)` at the head of the next group means: its rows are staged and its successor's ids are here, while
+// this group's stores may still be on their way.
+__device__ __forceinline__ void dma16(const float* g, uint32_t lds_base) {
+  // (m0 is a reserved register: the compiler only sets it right in front of an instruction that reads it)
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const float* p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
+}
+constexpr int kFwdStage = 4 * 16 * 64;   // floats per wave: P_U, P_I, GMF_U, GMF_I rows of sixteen samples
+constexpr int kFwdStores = 6;            // ranks, y1 x 2, y2, y3, prob
+
+// DBG != 0: timing experiments (dev/r03_ablate.sh; results are wrong): 2 no layers, 4 no y stores, 16 no prob store, 32 no row fetch
+template <int DBG>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 ncfp_fwd_kernel(const Tower T, int64_t m, const Fwd F) {
-  __shared__ __attribute__((aligned(16))) float s_w[kWFloats];
-  __shared__ __attribute__((aligned(16))) float s_b[kBFloats];
-  __shared__ __attribute__((aligned(16))) float s_hw[kHeadW + 4];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* s_w = lds;                                   // kWFloats
+  float* s_b = s_w + kWFloats;                        // kBFloats
+  float* s_hw = s_b + kBFloats;                       // kHeadW + 4 (+ 4 pad)
   const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* stage = s_hw + 80 + wave * kFwdStage;        // this wave's rows: [table][row][chunk ^ row] x 16 bytes
+  const uint32_t stage_addr = lds_addr(stage);
   const int64_t groups = (m + 15) / 16;
   const int64_t wave0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * kThreads) >> 6;
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  const float* pu = F.ptab;
-  const float* pi = F.ptab + F.ids.nu * kN0;
-  // operands of a group: ids -> (rank atomics) -> rows; the next group's are requested while this one computes
-  int64_t un = 0, in_ = 0;
-  auto fetch_ids = [&](int64_t g) {
-    const int64_t row = g * 16 + n;
-    un = in_ = 0;
-    if (g < groups && row < m) {
-      un = F.ids.uidx[row * F.ids.ustride];
-      in_ = F.ids.iidx[row * F.ids.istride];
+  const uint32_t nu = (uint32_t)F.ids.nu, ni = (uint32_t)F.ids.ni;
+  const float* tabs[4] = {F.ptab, F.ptab + F.ids.nu * kN0, F.gmf_u, F.gmf_i};
+  // stage 1: the two ids of this lane's sample (sample n of the group, the same in its four lanes)
+  int64_t idu = 0, idi = 0;
+  auto issue_ids = [&](int64_t g) {
+    int64_t row = g * 16 + n;
+    row = row < m ? row : m - 1;
+    if constexpr (DBG & 8) {
+      idu = (row * 7) % F.ids.nu;
+      idi = (row * 13) % F.ids.ni;
+    } else {
+      idu = F.ids.uidx[row * F.ids.ustride];
+      idi = F.ids.iidx[row * F.ids.istride];
     }
   };
-  struct Ops {
-    f32x4 a[4];      // P_U + P_I, columns 16j + 4q ..
-    f32x4 xe[4];     // GMF_U * GMF_I, columns 16q + 4i ..
-    int rank;        // q == 0: rank in the user row, q == 1: in the item row
-  };
-  auto fetch = [&](int64_t g, Ops& o) {
-    const int64_t row = g * 16 + n;
-    const bool live = g < groups && row < m;
-    int64_t u = un, i = in_;
-    const bool ubad = u < 0 || u >= F.ids.nu, ibad = i < 0 || i >= F.ids.ni;
+  // stage 2: rank atomics, then the four rows of every sample of the group by LDS-DMA.  Instruction k of a table moves
+  // rows 4k .. 4k+3: lane l fetches chunk (l % 16) ^ row of row 4k + l / 16 into slot (row, l % 16).
+  auto issue_rows = [&](int64_t g, int& rank) {
+    const bool live = g * 16 + n < m;
+    const bool ubad = (uint64_t)idu >= nu, ibad = (uint64_t)idi >= ni;
+    const uint32_t u = ubad ? 0u : (uint32_t)idu, i = ibad ? 0u : (uint32_t)idi;
     if (live && (ubad || ibad) && F.err_flag) *F.err_flag = 1;
-    if (ubad) u = 0;
-    if (ibad) i = 0;
-    o.rank = -1;
-    if (F.counts && live) {
-      if (q == 0 && !ubad) o.rank = atomicAdd(F.counts + u, 1);
-      if (q == 1 && !ibad) o.rank = atomicAdd(F.counts + F.ids.nu + i, 1);
+    rank = -1;
+    if (F.counts && live) {   // rank of the sample inside its row: the slot the backward stores its gradient row to
+      if (q == 0 && !ubad) rank = atomicAdd(F.counts + u, 1);
+      if (q == 1 && !ibad) rank = atomicAdd(F.counts + nu + i, 1);
     }
-    const float* ru = pu + u * kN0 + 4 * q;
-    const float* ri = pi + i * kN0 + 4 * q;
-    const float* gu = F.gmf_u + u * kP + 16 * q;
-    const float* gi = F.gmf_i + i * kP + 16 * q;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o.a[j] = live ? ldg4(ru + 16 * j) + ldg4(ri + 16 * j) : zero4;
+    for (int k = 0; k < 4; ++k) {
+      const int r = 4 * k + q;                          // the row this lane helps to fetch
+      const int src = (lane & 48) | r;                  // a lane of this quarter that holds sample r's ids
+      const uint32_t ur = (uint32_t)__shfl((int)u, src, 64), ir = (uint32_t)__shfl((int)i, src, 64);
+      const uint32_t col = 4u * (uint32_t)(n ^ r);      // swizzled 16-byte chunk of the row
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o.xe[j] = live ? ldg4(gu + 4 * j) * ldg4(gi + 4 * j) : zero4;
+      for (int t = 0; t < 4; ++t) {
+        const float* g_ = tabs[t] + ((t & 1) ? ir : ur) * 64u + col;
+        if constexpr (DBG & 32) asm volatile("" ::"v"(g_));
+        else dma16(g_, stage_addr + (uint32_t)((t * 16 + 4 * k) * 256));
+      }
+    }
   };
-  Ops cur, nxt;
-  fetch_ids(wave0);
+  // operand of table t, input block j: row n, chunk (4j + q) ^ n
+  auto staged = [&](int t, int j) {
+    return *reinterpret_cast<const f32x4*>(stage + (t * 16 + n) * 64 + 4 * ((4 * j + q) ^ n));
+  };
+  int stamp = 0;
+  (void)stamp;
+  STAMP(0, stamp++);
+  int rank_next = -1;
+  issue_ids(wave0);
   {
     f32x4 wv[kFStagePer];
     int wdst[kFStagePer];
@@ -191,64 +251,94 @@ ncfp_fwd_kernel(const Tower T, int64_t m, const Fwd F) {
     stage_forward_load(T, wv, wdst, bv);
     float hw = 0.0f;
     if (threadIdx.x <= kHeadW) hw = F.wfold[threadIdx.x];
-    fetch(wave0, cur);
-    fetch_ids(wave0 + nwaves);
+    issue_rows(wave0, rank_next);      // (waits for the ids alone: loads return in order)
+    issue_ids(wave0 + nwaves);
     stage_forward_store(s_w, s_b, wv, wdst, bv);
     if (threadIdx.x <= kHeadW) s_hw[threadIdx.x] = hw;
   }
   __syncthreads();
+  STAMP(0, stamp++);
   const float hc = s_hw[kHeadW];
+  if (wave0 >= groups) return;
+  // the first group's rows: everything issued so far (no stores yet).  The ids are "used" right behind every hand-placed
+  // wait: the compiler then places ITS wait for them there, in straight-line code where it can count the stores behind
+  // them, instead of a vmcnt(0) at the loop header (which is reached from two paths with different stores in flight)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("" : "+v"(idu), "+v"(idi));
   for (int64_t g = wave0; g < groups; g += nwaves) {
     const int64_t row = g * 16 + n;
-    const bool live = row < m;
-    fetch(g + nwaves, nxt);
-    fetch_ids(g + 2 * nwaves);
-    if (F.ranks && live && q < 2) F.ranks[(int64_t)q * m + row] = cur.rank;
-    f32x4 a0[4], y1[2], y2[1], y3[1];
+    const int64_t srow = row < m ? row : m;             // lanes without a sample store to the spare row m
+    // staged rows of g -> operands
+    f32x4 a0[4], xe[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 z = staged(0, j) + staged(1, j);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) a0[j][r] = fmaxf(cur.a[j][r], 0.0f);
-    layer_fwd<0, 4>(s_w, s_b, lane, q, a0, y1);
-    if (live) {
-#pragma unroll
-      for (int b = 0; b < 2; ++b) stg4(T.y[0] + row * T.ldy[0] + 16 * b + 4 * q, y1[b]);
+      for (int r = 0; r < 4; ++r) a0[j][r] = fmaxf(z[r], 0.0f);
     }
-    layer_fwd<1, 2>(s_w, s_b, lane, q, y1, y2);
-    if (live) stg4(T.y[1] + row * T.ldy[1] + 4 * q, y2[0]);
-    layer_fwd<2, 1>(s_w, s_b, lane, q, y2, y3);
-    if (live && q < 2) stg4(T.y[2] + row * T.ldy[2] + 4 * q, y3[0]);
+    // the head's extra columns 16q .. 16q+15 of this sample: chunks 4q + i
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      xe[i] = *reinterpret_cast<const f32x4*>(stage + (2 * 16 + n) * 64 + 4 * ((4 * q + i) ^ n)) *
+              *reinterpret_cast<const f32x4*>(stage + (3 * 16 + n) * 64 + 4 * ((4 * q + i) ^ n));
+    const int rank = rank_next;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is read: it may be overwritten
+    STAMP(0, stamp++);
+    issue_rows(g + nwaves, rank_next);
+    issue_ids(g + 2 * nwaves);
+    if constexpr (!(DBG & 64)) F.ranks[(q < 2 ? srow : m) * 2 + (q & 1)] = rank;
+    else asm volatile("" ::"v"(rank));
+    STAMP(0, stamp++);
+    f32x4 y1[2], y2[1], y3[1];
+    if constexpr (DBG & 2) {
+      y1[0] = a0[0] + a0[2]; y1[1] = a0[1] + a0[3]; y2[0] = y1[0] * y1[1]; y3[0] = y2[0] + y1[0];
+    } else {
+      layer_fwd<0, 4>(s_w, s_b, lane, q, a0, y1);
+      layer_fwd<1, 2>(s_w, s_b, lane, q, y1, y2);
+      layer_fwd<2, 1>(s_w, s_b, lane, q, y2, y3);
+    }
+    STAMP(0, stamp++);
+    if constexpr (!(DBG & 4)) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) stg4(T.y[0] + srow * T.ldy[0] + 16 * b + 4 * q, y1[b]);
+      stg4(T.y[1] + srow * T.ldy[1] + 4 * q, y2[0]);
+      stg4(T.y[2] + (q < 2 ? srow : m) * T.ldy[2] + 4 * (q & 1), y3[0]);
+    }
     // head: prob = act([gmf | h] . wfold + cfold); the four lanes of a sample hold 16 + (q < 2 ? 4 : 0) terms each
     float dot = 0.0f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const f32x4 wv = *reinterpret_cast<const f32x4*>(s_hw + 16 * q + 4 * i);
-      dot = fmaf(cur.xe[i][0], wv[0], dot); dot = fmaf(cur.xe[i][1], wv[1], dot);
-      dot = fmaf(cur.xe[i][2], wv[2], dot); dot = fmaf(cur.xe[i][3], wv[3], dot);
+      dot = fmaf(xe[i][0], wv[0], dot); dot = fmaf(xe[i][1], wv[1], dot);
+      dot = fmaf(xe[i][2], wv[2], dot); dot = fmaf(xe[i][3], wv[3], dot);
     }
-    if (q < 2) {
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(s_hw + kP + 4 * q);
-      dot = fmaf(y3[0][0], wv[0], dot); dot = fmaf(y3[0][1], wv[1], dot);
-      dot = fmaf(y3[0][2], wv[2], dot); dot = fmaf(y3[0][3], wv[3], dot);
+    {
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(s_hw + kP + 4 * (q & 1));
+      float d2 = y3[0][0] * wv[0];
+      d2 = fmaf(y3[0][1], wv[1], d2); d2 = fmaf(y3[0][2], wv[2], d2); d2 = fmaf(y3[0][3], wv[3], d2);
+      dot += q < 2 ? d2 : 0.0f;
     }
     dot += __shfl_xor(dot, 16, 64);
     dot += __shfl_xor(dot, 32, 64);
-    if (q == 0 && live) F.out[row * F.ldout] = ctr_act(dot + hc, F.act);
-    cur = nxt;
+    if constexpr (!(DBG & 16)) F.out[srow * F.ldout] = ctr_act(dot + hc, F.act);   // (the four lanes of a sample agree)
+    else asm volatile("" ::"v"(dot));
+    STAMP(0, stamp++);
+    // the next group's rows and its successor's ids are older than this group's kFwdStores stores
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(((DBG & 4) ? ((DBG & 16) ? 1 : 2) : kFwdStores) - ((DBG & 64) ? 1 : 0)) : "memory");
+    asm volatile("" : "+v"(idu), "+v"(idi));
   }
 }
 
 // ------------------------------------------------------------------ backward, per sample
-// slab a workgroup leaves in the workspace: [dW_l | db_l] for the three layers, then the head's sums in the layout
-// ctr_reduce_segments_fold expects (64 zeros -- the GMF part comes from the table rows, ncfp_finish -- then
-// sum gz * h (8) and sum gz)
+// slab a workgroup leaves in the workspace: [dW_l | db_l] for the three layers, then sum gz * h (8) and sum gz (the
+// GMF part of the head's weight gradient comes from the table rows, ncfp_finish)
 constexpr int slab_w(int l) {
   int o = 0;
   for (int i = 0; i < l; ++i) o += kN[i] * kK[i] + kN[i];
   return o;
 }
 constexpr int kSlabHead = slab_w(kL);                     // 2744
-constexpr int kSlab = kSlabHead + kHeadW + 1;             // 2817
+constexpr int kSlab = kSlabHead + kNL + 1 + 3;            // 2756 (a multiple of 4)
 constexpr int kVecs = 8 + 2 + 1;                          // dW accumulator vectors of a lane
 constexpr int kSmall = 32 + 16 + 8 + 8 + 1;               // bias sums, sum gz * h, sum gz
 constexpr int kCopy = kVecs * 256 + 68;                   // one wave's sums parked in LDS (16-byte multiple)
@@ -262,7 +352,7 @@ struct Bwd {
   const float* gprob; int64_t ldgp;
   int act;
   const int32_t* counts;                       // (nu + ni) from the forward
-  const int32_t* ranks;                        // (2, m)
+  const int32_t* ranks;                        // (m + 1, 2)
   float* gz;                                   // (2m, 64): buckets, user rows' slots first
   float* aux;                                  // (2m, 4): {gz, partner id, row, -} per slot
   int32_t* offsets;                            // (nu + ni + 1): written by workgroup 0 for the later launches
@@ -287,6 +377,7 @@ ncfp_bwd_kernel(const Tower T, int64_t m, const Bwd B) {
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const float* pu = B.ptab;
   const float* pi = B.ptab + B.ids.nu * kN0;
+  const uint32_t nu = (uint32_t)B.ids.nu, ni = (uint32_t)B.ids.ni;
 
   // ---- clear what this call accumulates into (both 16-byte aligned multiples of 4 floats)
   {
@@ -295,58 +386,64 @@ ncfp_bwd_kernel(const Tower T, int64_t m, const Bwd B) {
     if (B.zero_b)
       for (int64_t i = t0; i < B.zero_b_floats; i += step) stg4(B.zero_b + i, zero4);
   }
-  // ---- operands of a sample group (sample-major "d": this lane's sample lo, units 4q + r; unit-major "t": unit lo,
-  // samples 4q + c), requested a group ahead
-  struct Ops {
-    float gp, pb;
-    f32x4 y3d, y2d, y1d[2], a0d[4];
-    f32x4 y2t, y1t[2], a0t[4];
-    int su, si;          // bucket slots of this lane's sample (-1: none)
-    int uu, ii;          // its ids (row / partner of the slots)
+  // ---- the fetch pipeline (see the note above ncfp_fwd_kernel): stage 1 = the ids of this lane's sample; stage 2 = every
+  // operand of the group, raw.  Sample-major "d": this lane's sample lo, units 4q + r; unit-major "t": unit lo,
+  // samples 4q + c -- their ids come out of the row's other lanes (ds_bpermute), not out of memory a second time.
+  int64_t idu = 0, idi = 0;
+  auto issue_ids = [&](int64_t g) {
+    int64_t row = g * 16 + lo;
+    row = row < m ? row : m - 1;
+    idu = B.ids.uidx[row * B.ids.ustride];
+    idi = B.ids.iidx[row * B.ids.istride];
   };
-  auto fetch = [&](int64_t g, Ops& o) {
-    const int64_t row = g * 16 + lo;
-    const bool live = g < groups && row < m;
-    const int64_t rc = live ? row : m - 1;
-    int64_t rt[4];
+  struct Raw {
+    float gp, pb;
+    int ru, ri;                       // ranks of this lane's sample in its user / item row
+    uint32_t u, i;                    // its ids, clamped (bad ids: row 0, no slot)
+    bool ubad, ibad;
+    f32x4 y3d, y2d, y1d[2], pud[4], pid[4];
+    f32x4 y2t, y1t[2], put[4], pit[4];
+  };
+  auto issue_rows = [&](int64_t g, Raw& r) {
+    int64_t rc = g * 16 + lo;
+    rc = rc < m ? rc : m - 1;
+    r.ubad = (uint64_t)idu >= nu;
+    r.ibad = (uint64_t)idi >= ni;
+    r.u = r.ubad ? 0u : (uint32_t)idu;
+    r.i = r.ibad ? 0u : (uint32_t)idi;
+    r.gp = B.gprob[rc * B.ldgp];
+    r.pb = B.prob[rc * B.ldp];
+    r.ru = B.ranks[2 * rc];
+    r.ri = B.ranks[2 * rc + 1];
+    r.y3d = ldg4(T.y[2] + rc * T.ldy[2] + 4 * (q & 1));     // (8 units: lanes q >= 2 re-read q - 2's and drop them)
+    r.y2d = ldg4(T.y[1] + rc * T.ldy[1] + 4 * q);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int64_t r = g * 16 + 4 * q + c;
-      rt[c] = (g >= groups || r >= m) ? m - 1 : r;      // (a clamped row meets a zero gradient)
-    }
-    o.gp = live ? B.gprob[rc * B.ldgp] : 0.0f;           // a dead lane's gz is zero: it adds nothing anywhere
-    o.pb = B.prob[rc * B.ldp];
-    int64_t u = B.ids.uidx[rc * B.ids.ustride], i = B.ids.iidx[rc * B.ids.istride];
-    const bool ubad = u < 0 || u >= B.ids.nu, ibad = i < 0 || i >= B.ids.ni;
-    if (ubad) u = 0;
-    if (ibad) i = 0;
-    o.uu = (int)u; o.ii = (int)i;
-    const int ru = B.ranks[rc], ri = B.ranks[m + rc];
-    o.su = (live && !ubad && ru >= 0) ? ru : -1;          // + offset once the scan is there
-    o.si = (live && !ibad && ri >= 0) ? ri : -1;
-    o.y3d = q < 2 ? ldg4(T.y[2] + rc * T.ldy[2] + 4 * q) : zero4;
-    o.y2d = ldg4(T.y[1] + rc * T.ldy[1] + 4 * q);
-#pragma unroll
-    for (int b = 0; b < 2; ++b) o.y1d[b] = ldg4(T.y[0] + rc * T.ldy[0] + 16 * b + 4 * q);
+    for (int b = 0; b < 2; ++b) r.y1d[b] = ldg4(T.y[0] + rc * T.ldy[0] + 16 * b + 4 * q);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const f32x4 z = ldg4(pu + u * kN0 + 16 * j + 4 * q) + ldg4(pi + i * kN0 + 16 * j + 4 * q);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o.a0d[j][r] = fmaxf(z[r], 0.0f);
+      r.pud[j] = ldg4(pu + r.u * kN0 + 16 * j + 4 * q);
+      r.pid[j] = ldg4(pi + r.i * kN0 + 16 * j + 4 * q);
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      o.y2t[c] = T.y[1][rt[c] * T.ldy[1] + lo];
+      int64_t rt = g * 16 + 4 * q + c;
+      rt = rt < m ? rt : m - 1;                             // (a clamped row meets a zero gradient)
+      const int src = (lane & 48) | (4 * q + c);           // the lane of this row that holds sample 4q + c
+      const uint32_t uc = (uint32_t)__shfl((int)r.u, src, 64), ic = (uint32_t)__shfl((int)r.i, src, 64);
+      r.y2t[c] = T.y[1][rt * T.ldy[1] + lo];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) o.y1t[b][c] = T.y[0][rt[c] * T.ldy[0] + 16 * b + lo];
-      int64_t uc = B.ids.uidx[rt[c] * B.ids.ustride], ic = B.ids.iidx[rt[c] * B.ids.istride];
-      if (uc < 0 || uc >= B.ids.nu) uc = 0;
-      if (ic < 0 || ic >= B.ids.ni) ic = 0;
+      for (int b = 0; b < 2; ++b) r.y1t[b][c] = T.y[0][rt * T.ldy[0] + 16 * b + lo];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o.a0t[j][c] = fmaxf(pu[uc * kN0 + 16 * j + lo] + pi[ic * kN0 + 16 * j + lo], 0.0f);
+      for (int j = 0; j < 4; ++j) {
+        r.put[j][c] = pu[uc * kN0 + 16 * j + lo];
+        r.pit[j][c] = pi[ic * kN0 + 16 * j + lo];
+      }
     }
   };
-  Ops cur, nxt;
+  Raw rawA, rawB;
+  int stamp = 0;
+  (void)stamp;
+  STAMP(1, stamp++);
   // ---- what a lane sums over every group it walks
   f32x4 dw0[2][4], dw1[2], dw2;                // dW blocks: register r = row 4q + r, column lo
   f32x4 sb0[2], sb1, sb2, hy = zero4;          // bias sums of this lane's sample: units 4q + r
@@ -359,23 +456,41 @@ ncfp_bwd_kernel(const Tower T, int64_t m, const Bwd B) {
     for (int j = 0; j < 4; ++j) dw0[b][j] = zero4;
   }
   sb1 = sb2 = dw2 = zero4;
+  issue_ids(wave0);
   {
     f32x4 wv[kStagePer];
     int wdst[kStagePer];
     stage_transposed_load(T, wv, wdst);
-    fetch(wave0, cur);
+    const float hw = threadIdx.x <= kHeadW ? B.wfold[threadIdx.x] : 0.0f;
+    // the per-row sample counts into LDS, four coalesced loads in flight per thread (rows past the end re-read the last)
+    for (int64_t base = 0; base < nrows; base += 4 * kThreads) {
+      int v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t i = base + e * kThreads + threadIdx.x;
+        v[e] = B.counts[i < nrows ? i : nrows - 1];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int64_t i = base + e * kThreads + threadIdx.x;
+        if (i < nrows) s_off[i] = v[e];
+      }
+    }
+    issue_rows(wave0, rawA);
+    issue_ids(wave0 + nwaves);
     stage_transposed_store(s_wt, wv, wdst);
+    if (threadIdx.x <= kHeadW) s_hw[threadIdx.x] = hw;
   }
-  if (threadIdx.x <= kHeadW) s_hw[threadIdx.x] = B.wfold[threadIdx.x];
-  // ---- exclusive scan of the per-row sample counts (users, then items) into s_off: every workgroup for itself
+  __syncthreads();
+  STAMP(1, stamp++);   // weights staged, counts in LDS, first group requested
+  // ---- exclusive scan of the counts (users, then items), in place: every workgroup for itself
   {
     const int per = (int)((nrows + kThreads - 1) / kThreads);
     const int64_t i0 = (int64_t)threadIdx.x * per;
     int sum = 0;
     for (int e = 0; e < per; ++e)
-      if (i0 + e < nrows) sum += B.counts[i0 + e];
-    // inclusive scan of `sum` over the workgroup's threads
-    int inc = sum;
+      if (i0 + e < nrows) sum += s_off[i0 + e];
+    int inc = sum;   // inclusive scan of `sum` over the workgroup's threads
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const int v = __shfl_up(inc, d, 64);
@@ -388,25 +503,54 @@ ncfp_bwd_kernel(const Tower T, int64_t m, const Bwd B) {
     int run = base + inc - sum;
     for (int e = 0; e < per; ++e)
       if (i0 + e < nrows) {
+        const int c = s_off[i0 + e];
         s_off[i0 + e] = run;
-        run += B.counts[i0 + e];
+        run += c;
       }
     if (threadIdx.x == kThreads - 1) s_off[nrows] = base + inc;
     __syncthreads();
     if (blockIdx.x == 0)
       for (int64_t i = threadIdx.x; i <= nrows; i += kThreads) B.offsets[i] = s_off[i];
   }
+  STAMP(1, stamp++);   // scan done
 
-  for (int64_t g = wave0; g < groups; g += nwaves) {
-    fetch(g + nwaves, nxt);
+  // one group (see ncfp_fwd_kernel: unconditional stores, two named raw sets)
+  auto group = [&](int64_t g, Raw& raw, Raw& fill) {
+    const bool live = g * 16 + lo < m;
+    // ---- raw operands of g -> operands (the one wait of the iteration; it also brings the ids of g + nwaves)
+    const float gp = live ? raw.gp : 0.0f;                   // a dead lane's gz is zero: it adds nothing anywhere
+    const float pb = raw.pb;
+    const f32x4 y3d = q < 2 ? raw.y3d : zero4, y2d = raw.y2d, y2t = raw.y2t;
+    f32x4 y1d[2], y1t[2], a0d[4], a0t[4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      y1d[b] = raw.y1d[b];
+      y1t[b] = raw.y1t[b];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 zd = raw.pud[j] + raw.pid[j], zt = raw.put[j] + raw.pit[j];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a0d[j][r] = fmaxf(zd[r], 0.0f);
+        a0t[j][r] = fmaxf(zt[r], 0.0f);
+      }
+    }
+    const int uu = (int)raw.u, ii = (int)raw.i;
+    const int su = (live && !raw.ubad && raw.ru >= 0) ? raw.ru + s_off[uu] : -1;
+    const int si = (live && !raw.ibad && raw.ri >= 0) ? raw.ri + s_off[nu + ii] : -1;
+    STAMP(1, stamp++);   // operands converted (the wait)
+    issue_rows(g + nwaves, fill);
+    issue_ids(g + 2 * nwaves);
+    STAMP(1, stamp++);   // next group requested
     // ---- head: gz, the head's sums, the tower's (masked) gY
-    const float gzs = cur.gp * ctr_act_grad(cur.pb, B.act);
+    const float gzs = gp * ctr_act_grad(pb, B.act);
     if (q == 0) hc += gzs;
     f32x4 gz3[1];
     {
       const f32x4 wv = q < 2 ? *reinterpret_cast<const f32x4*>(s_hw + kP + 4 * q) : zero4;
-      hy += gzs * cur.y3d;                                    // (y3d is zero for q >= 2)
-      gz3[0] = relu_mask(gzs * wv, cur.y3d);
+      hy += gzs * y3d;                                        // (y3d is zero for q >= 2)
+      gz3[0] = relu_mask(gzs * wv, y3d);
     }
     sb2 += gz3[0];
     tiles_put<1>(tA, q, lo, gz3);
@@ -417,12 +561,12 @@ ncfp_bwd_kernel(const Tower T, int64_t m, const Bwd B) {
     {
       f32x4 tg[1];
       tiles_get<1>(tA, q, lo, tg);
-      dx_layer<2, 1>(s_wt, lane, gz3, w0, w1, [&](int, const f32x4& d0, const f32x4&) { gz2[0] = relu_mask(d0, cur.y2d); });
+      dx_layer<2, 1>(s_wt, lane, gz3, w0, w1, [&](int, const f32x4& d0, const f32x4&) { gz2[0] = relu_mask(d0, y2d); });
       sb1 += gz2[0];
       tiles_put<1>(tB, q, lo, gz2);
       dx_first<1>(s_wt, lane, w0, w1);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) dw2 = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[0][c], cur.y2t[c], dw2, 0, 0, 0);
+      for (int c = 0; c < 4; ++c) dw2 = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[0][c], y2t[c], dw2, 0, 0, 0);
     }
     // ---- layer 1 (32 -> 16)
     f32x4 gz1[2];
@@ -430,8 +574,8 @@ ncfp_bwd_kernel(const Tower T, int64_t m, const Bwd B) {
       f32x4 tg[1];
       tiles_get<1>(tB, q, lo, tg);
       dx_layer<1, 1>(s_wt, lane, gz2, w0, w1, [&](int, const f32x4& d0, const f32x4& d1) {
-        gz1[0] = relu_mask(d0, cur.y1d[0]);
-        gz1[1] = relu_mask(d1, cur.y1d[1]);
+        gz1[0] = relu_mask(d0, y1d[0]);
+        gz1[1] = relu_mask(d1, y1d[1]);
       });
 #pragma unroll
       for (int b = 0; b < 2; ++b) sb0[b] += gz1[b];
@@ -440,45 +584,48 @@ ncfp_bwd_kernel(const Tower T, int64_t m, const Bwd B) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) dw1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[0][c], cur.y1t[j][c], dw1[j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) dw1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[0][c], y1t[j][c], dw1[j], 0, 0, 0);
     }
+    STAMP(1, stamp++);   // head + layers 2, 1 done
     // ---- layer 0 (64 -> 32): its input gradient, masked by relu'(z0), IS gz0 -- stored into the sample's two buckets
     {
       f32x4 tg[2];
       tiles_get<2>(tA, q, lo, tg);
-      const int su = cur.su < 0 ? -1 : cur.su + s_off[cur.uu];
-      const int si = cur.si < 0 ? -1 : cur.si + s_off[B.ids.nu + cur.ii];
-      float* du = B.gz + (int64_t)su * kN0 + 4 * q;
-      float* di = B.gz + (int64_t)si * kN0 + 4 * q;
+      // a sample without a slot (bad id, padding lane) writes to the spare row behind the buckets
+      float* du = B.gz + (int64_t)(su >= 0 ? su : 2 * m) * kN0 + 4 * q;
+      float* di = B.gz + (int64_t)(si >= 0 ? si : 2 * m) * kN0 + 4 * q;
       dx_layer<0, 2>(s_wt, lane, gz1, w0, w1, [&](int j, const f32x4& d0, const f32x4& d1) {
-        const f32x4 g0 = relu_mask(d0, cur.a0d[j]), g1 = relu_mask(d1, cur.a0d[j + 1]);
-        if (su >= 0) {
-          stg4(du + 16 * j, g0);
-          stg4(du + 16 * (j + 1), g1);
-        }
-        if (si >= 0) {
-          stg4(di + 16 * j, g0);
-          stg4(di + 16 * (j + 1), g1);
-        }
+        const f32x4 g0 = relu_mask(d0, a0d[j]), g1 = relu_mask(d1, a0d[j + 1]);
+        stg4(du + 16 * j, g0);
+        stg4(du + 16 * (j + 1), g1);
+        stg4(di + 16 * j, g0);
+        stg4(di + 16 * (j + 1), g1);
       });
-      if (q == 0) {
-        if (su >= 0) stg4(B.aux + (int64_t)su * 4, f32x4{gzs, __int_as_float(cur.ii), __int_as_float(cur.uu), 0.0f});
-        if (si >= 0)
-          stg4(B.aux + (int64_t)si * 4, f32x4{gzs, __int_as_float(cur.uu), __int_as_float((int)B.ids.nu + cur.ii), 0.0f});
-      }
+      // (the four lanes of a sample write the same record: an unconditional, countable store)
+      stg4(B.aux + (int64_t)(su >= 0 ? su : 2 * m) * 4, f32x4{gzs, __int_as_float(ii), __int_as_float(uu), 0.0f});
+      stg4(B.aux + (int64_t)(si >= 0 ? si : 2 * m) * 4, f32x4{gzs, __int_as_float(uu), __int_as_float((int)nu + ii), 0.0f});
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            dw0[b][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[b][c], cur.a0t[j][c], dw0[b][j], 0, 0, 0);
+            dw0[b][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[b][c], a0t[j][c], dw0[b][j], 0, 0, 0);
     }
-    cur = nxt;
+    STAMP(1, stamp++);   // layer 0 done
+  };
+  if (wave0 < groups) {
+    group(wave0, rawA, rawB);                        // peeled, as in ncfp_fwd_kernel
+    for (int64_t g = wave0 + nwaves; g < groups; g += 2 * nwaves) {
+      group(g, rawB, rawA);
+      if (g + nwaves >= groups) break;
+      group(g + nwaves, rawA, rawB);
+    }
   }
 
   // ---- the workgroup's partial: every wave parks its sums (the weights and tiles are dead), then the slab is summed
   // over the four copies on the way out
+  STAMP(1, stamp++);   // loop end
   __syncthreads();
   {
     auto rsum = [&](const f32x4& v) {
@@ -525,27 +672,124 @@ ncfp_bwd_kernel(const Tower T, int64_t m, const Bwd B) {
     if (i < 32) dst = slab_w(0) + kN[0] * kK[0] + i;
     else if (i < 48) dst = slab_w(1) + kN[1] * kK[1] + (i - 32);
     else if (i < 56) dst = slab_w(2) + kN[2] * kK[2] + (i - 48);
-    else dst = kSlabHead + kP + (i - 56);                          // 8 x (gz * h), then sum gz
+    else dst = kSlabHead + (i - 56);                               // 8 x (gz * h), then sum gz
     out[dst] = sum4(at);
   }
-  for (int i = threadIdx.x; i < kP; i += kThreads) out[kSlabHead + i] = 0.0f;   // the GMF part: ncfp_finish
+  STAMP(1, stamp++);   // slab written
 }
 
 // ------------------------------------------------------------------ segment sums over the buckets
 // ST[v] = [ S[v] (64) | T[v] (64) ],  S[v] = sum of the gz0 rows in row v's bucket,  T[v] = sum gz_b * partner row.
 // A lane group of sixteen owns sixteen consecutive SLOTS, whatever rows they belong to: equal work per wave under any
-// id distribution.  It keeps running sums for the row it is in and adds them to ST when the row changes (and at its
-// end): one 64-byte atomic segment per sixteen lanes and quarter row, after a transposition through LDS (lane lo of
-// the loads holds columns 4lo .. 4lo+3; an atomic instruction wants sixteen consecutive floats from sixteen lanes).
+// id distribution.  Every load of the group is requested before any is consumed -- the slot records first (one round
+// trip), then the sixteen bucket rows and the sixteen partner rows they name (a second one): a load-use loop over the
+// slots was eight dependent round trips, 15 us for a kernel that moves 50 MB.  The group keeps running sums for the row
+// it is in and adds them to ST when the row changes (and at its end): one 64-byte atomic segment per sixteen lanes and
+// quarter row, after a transposition through LDS (lane lo of the loads holds columns 4lo .. 4lo+3; an atomic
+// instruction wants sixteen consecutive floats from sixteen lanes).
+//
+// The same launch carries, on workgroups of their own, the second pass over ncfp_bwd's slabs (tower dW / db: 32
+// outputs x 8 part-lanes per workgroup, fixed order) and the head fold's chain rule from the slabs' head sums
+// (ctr_fold_head_bwd's map without the GMF part): both only depend on ncfp_bwd, and run beside the segment sums
+// instead of in a launch of their own in front of them.
 struct Seg {
   const float* gz; const float* aux; const int32_t* offsets;
   const float* gmf_u; const float* gmf_i;
   int64_t nu, ni;
   float* st;                                   // (nu + ni, 128), zeroed
+  int seg_blocks, red_blocks;                  // roles by blockIdx.x: [0, seg) segment sums, [seg, seg + red) slabs, last: fold
+  const float* slabs; int parts;
+  float* gw[kL]; float* gb[kL];                // tower gradients (+=)
+  // head fold chain rule: u = linear2.weight (128), w / b = `linear` (64 x 8)
+  const float* fold_u; const float* fold_w; int64_t fold_ldw; const float* fold_b;
+  float* g_u; float* g_w; int64_t ld_g_w; float* g_b; float* g_b2;   // (+=), nullable
 };
+
+__device__ __forceinline__ void slab_reduce_role(const Seg& A, int blk) {
+  // outputs [32 blk, 32 blk + 32) of the kSlabHead tower sums: lane (o, pl) adds every 8th partial, 8 loads in flight
+  __shared__ float s_part[kWaves][32];
+  const int o = threadIdx.x & 31, pl = threadIdx.x >> 5, wave = threadIdx.x >> 6;
+  const int e = blk * 32 + o;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (e < kSlabHead) {
+    const float* src = A.slabs + e;
+    int p = pl;
+    for (; p + 7 * 8 < A.parts; p += 8 * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] += src[(int64_t)(p + 8 * u) * kSlab];
+    }
+    for (; p < A.parts; p += 8) acc[0] += src[(int64_t)p * kSlab];
+  }
+  float t = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  t += __shfl_xor(t, 32, 64);
+  if ((threadIdx.x & 63) < 32) s_part[wave][o] = t;
+  __syncthreads();
+  if (threadIdx.x < 32 && e < kSlabHead) {
+    const float total = (s_part[0][o] + s_part[1][o]) + (s_part[2][o] + s_part[3][o]);
+    // slab offset -> (layer, weight or bias element)
+    int l = 0, r = e;
+#pragma unroll
+    for (int i = 0; i < kL; ++i)
+      if (e >= slab_w(i)) { l = i; r = e - slab_w(i); }
+    const int wn = l == 0 ? kN[0] * kK[0] : l == 1 ? kN[1] * kK[1] : kN[2] * kK[2];
+    float* dst = r < wn ? A.gw[l] + r : A.gb[l] + (r - wn);
+    dst[0] += total;
+  }
+}
+
+__device__ __forceinline__ void head_fold_role(const Seg& A) {
+  // nine columns (sum gz * h [8], sum gz) x 28 part-lanes: every load of a thread in flight at once
+  __shared__ float s_p[28][12];
+  __shared__ float s_g[12];
+  const int col = threadIdx.x % 9, pl = threadIdx.x / 9;
+  float acc = 0.0f;
+  if (pl < 28) {
+    const float* src = A.slabs + kSlabHead + col;
+    float v[10];
+#pragma unroll
+    for (int u = 0; u < 10; ++u) v[u] = 0.0f;
+    for (int p0 = pl; p0 < A.parts; p0 += 28 * 10) {
+#pragma unroll
+      for (int u = 0; u < 10; ++u)
+        if (p0 + 28 * u < A.parts) v[u] += src[(int64_t)(p0 + 28 * u) * kSlab];
+    }
+#pragma unroll
+    for (int u = 0; u < 10; ++u) acc += v[u];
+    s_p[pl][col] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 9) {
+    float t = 0.0f;
+    for (int i = 0; i < 28; ++i) t += s_p[i][threadIdx.x];
+    s_g[threadIdx.x] = t;
+  }
+  __syncthreads();
+  const float* u = A.fold_u + kP;
+  const float gc = s_g[kNL];
+  for (int t = threadIdx.x; t < 64 * kNL; t += kThreads) {            // g `linear`.weight[i][q] += u[64 + i] * hy[q]
+    const int i = t / kNL, q = t % kNL;
+    if (A.g_w) A.g_w[(int64_t)i * A.ld_g_w + q] += u[i] * s_g[q];
+  }
+  if (threadIdx.x < 64) {
+    const int i = threadIdx.x;
+    if (A.g_u) {                                                      // g linear2.weight[64 + i]
+      float sacc = A.fold_b ? A.fold_b[i] * gc : 0.0f;
+#pragma unroll
+      for (int q = 0; q < kNL; ++q) sacc = fmaf(A.fold_w[(int64_t)i * A.fold_ldw + q], s_g[q], sacc);
+      A.g_u[kP + i] += sacc;
+    }
+    if (A.g_b) A.g_b[i] += u[i] * gc;
+  }
+  if (threadIdx.x == 64 && A.g_b2) A.g_b2[0] += gc;
+}
 
 __global__ void __launch_bounds__(kThreads)
 ncfp_segsum_kernel(const Seg A) {
+  if ((int)blockIdx.x >= A.seg_blocks) {
+    if ((int)blockIdx.x < A.seg_blocks + A.red_blocks) slab_reduce_role(A, (int)blockIdx.x - A.seg_blocks);
+    else head_fold_role(A);
+    return;
+  }
   __shared__ __attribute__((aligned(16))) float s_t[kThreads / 16][2][68];
   const int lane = threadIdx.x & 63, lo = lane & 15, grp = threadIdx.x >> 4;
   const int64_t total = A.offsets[A.nu + A.ni];
@@ -569,33 +813,27 @@ ncfp_segsum_kernel(const Seg A) {
     }
     asm volatile("" ::: "memory");
   };
+  f32x4 ax[16], g[16], p[16];
 #pragma unroll
-  for (int k0 = 0; k0 < 16; k0 += 4) {
-    f32x4 ax[4], g[4], p[4];
+  for (int k = 0; k < 16; ++k) ax[k] = ldg4(A.aux + (s0 + (k < cnt ? k : cnt - 1)) * 4);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int64_t s = s0 + (k0 + k < cnt ? k0 + k : cnt - 1);
-      ax[k] = ldg4(A.aux + s * 4);
-      g[k] = ldg4(A.gz + s * kN0 + 4 * lo);
-    }
+  for (int k = 0; k < 16; ++k) {
+    const int64_t s = s0 + (k < cnt ? k : cnt - 1);
+    const int pid = __float_as_int(ax[k][1]), v = __float_as_int(ax[k][2]);
+    g[k] = ldg4(A.gz + s * kN0 + 4 * lo);
+    p[k] = ldg4((v < A.nu ? A.gmf_i : A.gmf_u) + (int64_t)pid * kP + 4 * lo);
+  }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int pid = __float_as_int(ax[k][1]), v = __float_as_int(ax[k][2]);
-      const float* prow = (v < A.nu ? A.gmf_i : A.gmf_u) + (int64_t)pid * kP;
-      p[k] = ldg4(prow + 4 * lo);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (k0 + k < cnt) {
-        const int v = __float_as_int(ax[k][2]);
-        if (v != cur) {
-          if (cur >= 0) flush(cur);
-          cur = v;
-          accs = acct = zero4;
-        }
-        accs += g[k];
-        acct += ax[k][0] * p[k];
+  for (int k = 0; k < 16; ++k) {
+    if (k < cnt) {
+      const int v = __float_as_int(ax[k][2]);
+      if (v != cur) {
+        if (cur >= 0) flush(cur);
+        cur = v;
+        accs = acct = zero4;
       }
+      accs += g[k];
+      acct += ax[k][0] * p[k];
     }
   }
   if (cur >= 0) flush(cur);
@@ -645,21 +883,37 @@ ncfp_finish_kernel(const Fin A) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) colsum[j] = gw[j] = zero4;
   if (any) {
+    // every operand is requested before any is consumed: they are independent of each other, and a load-use order was
+    // eight dependent round trips on a handful of workgroups (12 us for 40 MFLOP)
     // ---- sample-major operands: this lane's row n, columns 16j + 4q ..
-    f32x4 sd[4], td[4], gd[4];
+    f32x4 sd[4], td[4], gd[4], og[4], ot[4], wf[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       sd[j] = live ? ldg4(st + row * 128 + 16 * j + 4 * q) : zero4;
       td[j] = live ? ldg4(st + row * 128 + 64 + 16 * j + 4 * q) : zero4;
       gd[j] = live ? ldg4(gmf + row * kP + 16 * j + 4 * q) : zero4;
+      og[j] = (live && ggmf) ? ldg4(ggmf + row * kP + 16 * j + 4 * q) : zero4;
+      ot[j] = (live && gtab) ? ldg4(gtab + row * kH + 16 * j + 4 * q) : zero4;
+      wf[j] = ldg4(A.wfold + 16 * j + 4 * q);
+    }
+    // ---- unit-major operands: unit / input n of rows 4q + c;  A operands of dMLP: W0[16j + 4q + c][coff + 16b + n]
+    f32x4 stt[4], xt[4], wt[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int64_t r = r0 + 4 * q + c;
+      const bool ok = r < rows;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        stt[b][c] = ok ? st[r * 128 + 16 * b + n] : 0.0f;
+        xt[b][c] = ok ? tab[r * kH + 16 * b + n] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wt[j][b][c] = A.w0[(int64_t)(16 * j + 4 * q + c) * A.ldw0 + coff + 16 * b + n];
+      }
     }
     // dGMF[row] += wfold[:64] * T[row];   sum_rows GMF * T
     if (ggmf && live) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float* d = ggmf + row * kP + 16 * j + 4 * q;
-        stg4(d, ldg4(d) + ldg4(A.wfold + 16 * j + 4 * q) * td[j]);
-      }
+      for (int j = 0; j < 4; ++j) stg4(ggmf + row * kP + 16 * j + 4 * q, og[j] + wf[j] * td[j]);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -668,40 +922,20 @@ ncfp_finish_kernel(const Fin A) {
     }
     // ---- dMLP^T (64 inputs x 16 rows) = W0half^T (64 x 64 units) . S^T (64 units x 16 rows)
     if (gtab) {
-      f32x4 acc[4] = {zero4, zero4, zero4, zero4};
+      f32x4 acc[4] = {ot[0], ot[1], ot[2], ot[3]};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x4 wt[4];   // A operands: W0[16j + 4q + c][coff + 16b + n]
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) wt[b][c] = A.w0[(int64_t)(16 * j + 4 * q + c) * A.ldw0 + coff + 16 * b + n];
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-          for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[b][c], sd[j][c], acc[b], 0, 0, 0);
-      }
+          for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wt[j][b][c], sd[j][c], acc[b], 0, 0, 0);
       if (live) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          float* d = gtab + row * kH + 16 * b + 4 * q;
-          stg4(d, ldg4(d) + acc[b]);
-        }
+        for (int b = 0; b < 4; ++b) stg4(gtab + row * kH + 16 * b + 4 * q, acc[b]);
       }
     }
-    // ---- dW0half (64 units x 64 inputs) += S^T . X: unit-major operands, unit / input n of rows 4q + c
+    // ---- dW0half (64 units x 64 inputs) += S^T . X
     if (A.g_w0) {
-      f32x4 stt[4], xt[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int64_t r = r0 + 4 * q + c;
-        const bool ok = r < rows;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          stt[b][c] = ok ? st[r * 128 + 16 * b + n] : 0.0f;
-          xt[b][c] = ok ? tab[r * kH + 16 * b + n] : 0.0f;
-        }
-      }
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -776,13 +1010,20 @@ bool pattern_ok(const ctr_ncf_proj_t* d) {
 
 }  // namespace
 
+#ifdef CTR_STAMPS
+extern "C" __attribute__((visibility("default"))) int ctr_ncfp_debug_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 128);
+}
+#endif
+
 static int64_t workspace_floats(int64_t batch, int64_t num_users, int64_t num_items) {
   const int64_t rows = num_users + num_items;
   const int64_t groups = ctr_ceil_div(batch > 0 ? batch : 1, 16);
   int64_t grid = ctr_ceil_div(groups, kWaves);
   if (grid > 768) grid = 768;
-  // buckets (2B, 64) | slot records (2B, 4) | segment sums (rows, 128) | 128 scratch | offsets (rows + 1) | slabs
-  return 2 * batch * kN0 + 2 * batch * 4 + rows * 128 + 128 + (rows + 1 + 3) / 4 * 4 + grid * (int64_t)kSlab;
+  // buckets (2B + 1, 64) | slot records (2B + 1, 4) | segment sums (rows, 128) | offsets (rows + 1) | slabs
+  // (the spare slot 2B takes the stores of samples without a slot: bad ids, the padding lanes of the last group)
+  return (2 * batch + 1) * kN0 + (2 * batch + 1) * 4 + rows * 128 + (rows + 1 + 3) / 4 * 4 + grid * (int64_t)kSlab;
 }
 
 extern "C" int ctr_ncf_proj_workspace_floats(int64_t batch, int64_t num_users, int64_t num_items, int64_t* floats) {
@@ -796,7 +1037,7 @@ extern "C" int ctr_ncf_proj_fwd(const ctr_ncf_proj_t* d, void* stream) {
   if (!pattern_ok(d)) return CTR_ELIMIT;
   CTR_REQUIRE(d->prob && d->ldprob >= 1 && d->head_act >= CTR_ACT_NONE && d->head_act <= CTR_ACT_SIGMOID, CTR_EINVAL);
   CTR_REQUIRE(d->ld_proj_w >= d->proj_k, CTR_EINVAL);
-  CTR_REQUIRE(!d->training || (d->counts && d->ranks), CTR_EINVAL);
+  CTR_REQUIRE(d->ranks && (!d->training || d->counts), CTR_EINVAL);
   Tower T;
   int rc = fill_tower(&T, d->layers, true);
   if (rc != CTR_OK) return rc;
@@ -809,12 +1050,25 @@ extern "C" int ctr_ncf_proj_fwd(const ctr_ncf_proj_t* d, void* stream) {
   rc = ctr_launch_status();
   if (rc != CTR_OK || d->batch == 0) return rc;
   const Fwd F{Ids{d->user_idx, d->user_stride, d->item_idx, d->item_stride, nu, ni}, d->ptab, d->gmf_user, d->gmf_item,
-              d->wfold, d->prob, d->ldprob, d->head_act, d->err_flag, d->training ? d->counts : nullptr,
-              d->training ? d->ranks : nullptr};
+              d->wfold, d->prob, d->ldprob, d->head_act, d->err_flag, d->training ? d->counts : nullptr, d->ranks};
   const int64_t groups = ctr_ceil_div(d->batch, 16);
   int64_t grid = ctr_ceil_div(groups, kWaves);
-  if (grid > 256 * 4) grid = 256 * 4;
-  hipLaunchKernelGGL(ncfp_fwd_kernel, dim3((unsigned)grid), dim3(kThreads), 0, st, T, d->batch, F);
+  static const int fwd_wgs = [] { const char* e = getenv("CTR_NCFP_FWD_WGS"); return e ? atoi(e) : 512; }();
+  if (grid > fwd_wgs) grid = fwd_wgs;
+  static const int dbg = [] { const char* e = getenv("CTR_NCFP_DBG"); return e ? atoi(e) : 0; }();
+  constexpr size_t fwd_lds = sizeof(float) * (kWFloats + kBFloats + 80 + kWaves * kFwdStage);
+  switch (dbg) {
+#define CTR_DBG_CASE(V)                                                                                                  \
+  case V:                                                                                                                \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(ncfp_fwd_kernel<V>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (int)fwd_lds) != hipSuccess)                                                                 \
+      return CTR_ELAUNCH;                                                                                                \
+    hipLaunchKernelGGL(ncfp_fwd_kernel<V>, dim3((unsigned)grid), dim3(kThreads), fwd_lds, st, T, d->batch, F);           \
+    break
+    CTR_DBG_CASE(54); CTR_DBG_CASE(62); CTR_DBG_CASE(118); CTR_DBG_CASE(126); CTR_DBG_CASE(64); CTR_DBG_CASE(8); CTR_DBG_CASE(72);
+    default: CTR_DBG_CASE(0);
+#undef CTR_DBG_CASE
+  }
   return ctr_launch_status();
 }
 
@@ -833,18 +1087,18 @@ extern "C" int ctr_ncf_proj_bwd(const ctr_ncf_proj_t* d, const ctr_ncf_proj_grad
   CTR_REQUIRE(g->workspace_floats >= workspace_floats(m, nu, ni) && ctr_aligned16(g->workspace), CTR_ELIMIT);
   // carve the workspace
   float* ws = g->workspace;
-  float* gzb = ws;            ws += 2 * m * kN0;
-  float* aux = ws;            ws += 2 * m * 4;
+  float* gzb = ws;            ws += (2 * m + 1) * kN0;
+  float* aux = ws;            ws += (2 * m + 1) * 4;
   float* stt = ws;            ws += rows * 128;
-  float* scratch = ws;        ws += 128;   // cleared with the segment sums: the fold kernel accumulates its 73 sums here
   int32_t* offs = reinterpret_cast<int32_t*>(ws); ws += (rows + 1 + 3) / 4 * 4;
   float* slabs = ws;
   const int64_t groups = ctr_ceil_div(m, 16);
   int64_t grid = ctr_ceil_div(groups, kWaves);
-  if (grid > 768) grid = 768;
+  static const int bwd_wgs = [] { const char* e = getenv("CTR_NCFP_BWD_WGS"); return e ? atoi(e) : 256; }();
+  if (grid > bwd_wgs) grid = bwd_wgs;
   const Ids ids{d->user_idx, d->user_stride, d->item_idx, d->item_stride, nu, ni};
   const Bwd B{ids, d->ptab, d->wfold, d->prob, d->ldprob, g->gprob, g->ldgprob, d->head_act, d->counts, d->ranks, gzb, aux,
-              offs, slabs, stt, rows * 128 + 128, g->zero_buf, g->zero_buf ? g->zero_floats : 0};
+              offs, slabs, stt, rows * 128, g->zero_buf, g->zero_buf ? g->zero_floats : 0};
   const int64_t main_f = kWFloats + kWaves * kStripP + (rows + 1 + 3) / 4 * 4, copy_f = (int64_t)kWaves * kCopy;
   const size_t lds_bytes = sizeof(float) * (size_t)(main_f > copy_f ? main_f : copy_f);
   CTR_REQUIRE(lds_bytes <= 150 * 1024, CTR_ELIMIT);
@@ -854,22 +1108,16 @@ extern "C" int ctr_ncf_proj_bwd(const ctr_ncf_proj_t* d, const ctr_ncf_proj_grad
   hipLaunchKernelGGL(ncfp_bwd_kernel, dim3((unsigned)grid), dim3(kThreads), lds_bytes, st, T, m, B);
   rc = ctr_launch_status();
   if (rc != CTR_OK) return rc;
-  // tower dW / db partials and the head fold's chain rule (its GMF part arrives from ncfp_finish)
-  CtrSegments segs;
-  segs.n = 0;
-  int64_t off = 0;
-  for (int l = 1; l <= kL; ++l) {
-    const int64_t wn = (int64_t)d->layers[l].n * d->layers[l].k;
-    segs.s[segs.n++] = CtrSegment{off, wn, g->layers[l].gw};
-    segs.s[segs.n++] = CtrSegment{off + wn, d->layers[l].n, g->layers[l].gb};
-    off += wn + d->layers[l].n;
+  // segment sums over the buckets, and beside them (own workgroups) the tower's dW / db partials and the head fold's
+  // chain rule (its GMF part arrives from ncfp_finish)
+  Seg S{gzb, aux, offs, d->gmf_user, d->gmf_item, nu, ni, stt, (int)ctr_ceil_div(2 * m, kThreads), (kSlabHead + 31) / 32,
+        slabs, (int)grid, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, d->head_w, d->proj_w, d->ld_proj_w,
+        d->proj_b, g->g_head_w, g->g_proj_w, g->ld_g_proj_w, g->g_proj_b, g->g_head_b};
+  for (int l = 0; l < kL; ++l) {
+    S.gw[l] = g->layers[l + 1].gw;
+    S.gb[l] = g->layers[l + 1].gb;
   }
-  const CtrHeadFoldGrad F{d->head_w, d->proj_w, d->ld_proj_w, d->proj_b, scratch, scratch + kHeadW, g->g_head_w, g->g_proj_w,
-                          g->ld_g_proj_w, g->g_proj_b, g->g_head_b};
-  rc = ctr_reduce_segments_fold(slabs, (int)grid, kSlab, segs, off, F, st);
-  if (rc != CTR_OK) return rc;
-  const Seg S{gzb, aux, offs, d->gmf_user, d->gmf_item, nu, ni, stt};
-  hipLaunchKernelGGL(ncfp_segsum_kernel, dim3((unsigned)ctr_ceil_div(2 * m, kThreads)), dim3(kThreads), 0, st, S);
+  hipLaunchKernelGGL(ncfp_segsum_kernel, dim3((unsigned)(S.seg_blocks + S.red_blocks + 1)), dim3(kThreads), 0, st, S);
   rc = ctr_launch_status();
   if (rc != CTR_OK) return rc;
   const Fin N{stt, d->mlp_user, d->mlp_item, d->gmf_user, d->gmf_item, d->layers[0].w, d->layers[0].k, d->wfold, nu, ni,

@@ -634,10 +634,12 @@ class NcfProj:
         m, rows = self.batch, self.nu + self.ni
         self.ptab = torch.empty((rows, hidden[0].weight.shape[0]), dtype=torch.float32, device=dev)
         self.wfold = torch.empty(76, dtype=torch.float32, device=dev)
-        self.ys = [torch.empty((m, layer.weight.shape[0]), dtype=torch.float32, device=dev) for layer in hidden[1:]]
-        self.prob = torch.empty((m, 1), dtype=torch.float32, device=dev)
+        # every per-sample buffer has a spare row m: lanes without a sample store there (unconditional, countable stores)
+        self.ys = [torch.empty((m + 1, layer.weight.shape[0]), dtype=torch.float32, device=dev) for layer in hidden[1:]]
+        self.prob_buf = torch.empty((m + 1, 1), dtype=torch.float32, device=dev)
+        self.prob = self.prob_buf[:m]
         self.counts = torch.empty(rows, dtype=torch.int32, device=dev) if training else None
-        self.ranks = torch.empty(2 * m, dtype=torch.int32, device=dev) if training else None
+        self.ranks = torch.empty(2 * (m + 1), dtype=torch.int32, device=dev)   # (written in inference too: no conditional store)
         self.err_flag, self.training = err_flag, training
 
     def _desc(self):

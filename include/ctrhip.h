@@ -445,10 +445,12 @@ int ctr_embed_mlp_head_bwd(const ctr_field_t* fields, int nfields, int64_t batch
  * layers = {128->64, 64->32, 32->16, 16->8} all ReLU with biases, proj (`linear`) 8 -> 64, head (`linear2`) on
  * [gmf | linear(h)] (128 weights), num_users + num_items <= CTR_NCF_PROJ_MAX_ROWS, 16-byte aligned tables.
  * layers[0].y is not used (the first layer's output never exists per sample); layers[1..3].y are the saved
- * activations (m, 32), (m, 16), (m, 8) the forward writes and the backward reads.
+ * activations (m + 1, 32), (m + 1, 16), (m + 1, 8) the forward writes and the backward reads.  EVERY per-sample
+ * buffer has one spare row behind the batch (prob: m + 1 elements; ranks: 2 (m + 1) int32): lanes without a sample
+ * store there, so that no store of the kernels is conditional.
  * Caller-owned buffers the forward fills for the backward: ptab (num_users + num_items, 64), wfold (76 floats),
- * and with training != 0: counts (num_users + num_items int32), ranks (2 * batch int32).  Parameters must not
- * change between the forward and the backward (the backward re-reads tables and ptab). */
+ * ranks (always), and with training != 0: counts (num_users + num_items int32).  Parameters must not change between the
+ * forward and the backward (the backward re-reads tables and ptab). */
 #define CTR_NCF_PROJ_MAX_ROWS 16384
 typedef struct ctr_ncf_proj {
   const int64_t* user_idx; int64_t user_stride;   /* ids of the batch, element strides */
