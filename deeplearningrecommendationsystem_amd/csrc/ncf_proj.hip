@@ -330,19 +330,29 @@ ncfp_fwd_kernel(const Tower T, int64_t m, const Fwd F) {
 }
 
 // ------------------------------------------------------------------ backward, per sample
-// slab a workgroup leaves in the workspace: [dW_l | db_l] for the three layers, then sum gz * h (8) and sum gz (the
-// GMF part of the head's weight gradient comes from the table rows, ncfp_finish)
+// slab a workgroup leaves in the workspace, in the order its lanes hold the sums (coalesced 16-byte stores; the second
+// pass, slab_reduce_role, does the index arithmetic once per output instead of every workgroup once per element):
+//   [vector v][lane][register r]: dW accumulator vectors  v < 8: layer 0 block (v / 4, v % 4);  8, 9: layer 1;  10: layer 2
+//   (register r of lane (q, lo) = row 16 b + 4 q + r, column 16 j + lo of its layer's weight gradient)
+//   then kSmall sums: layer-0 bias (32), layer-1 bias (16), layer-2 bias (8), sum gz * h (8), sum gz (1)
+// (the GMF part of the head's weight gradient comes from the table rows, ncfp_finish)
 constexpr int slab_w(int l) {
   int o = 0;
   for (int i = 0; i < l; ++i) o += kN[i] * kK[i] + kN[i];
   return o;
 }
-constexpr int kSlabHead = slab_w(kL);                     // 2744
-constexpr int kSlab = kSlabHead + kNL + 1 + 3;            // 2756 (a multiple of 4)
+constexpr int kSlabHead = slab_w(kL);                     // 2744 tower outputs: [dW_l | db_l] for the three layers
 constexpr int kVecs = 8 + 2 + 1;                          // dW accumulator vectors of a lane
 constexpr int kSmall = 32 + 16 + 8 + 8 + 1;               // bias sums, sum gz * h, sum gz
 constexpr int kCopy = kVecs * 256 + 68;                   // one wave's sums parked in LDS (16-byte multiple)
+constexpr int kSlab = kCopy;                              // 2884
 constexpr int kStripP = 3 * kTile;                        // per wave: tiles A0 A1 | B0
+// the staged operands of a sample group (floats, per wave): sixteen rows each of P_U, P_I, Y1, Y2, Y3 -- fetched
+// coalesced by LDS-DMA, 16-byte chunks XOR-swizzled with the row so that both read patterns (sample-major ds_read_b128,
+// unit-major ds_read_b32) spread over the banks
+constexpr int kSgPU = 0, kSgPI = 1024, kSgY1 = 2048, kSgY2 = 2560, kSgY3 = 2816, kBwdStage = 3072;
+constexpr int kBwdDma = 12;                               // row fetches per group
+constexpr int kBwdStores = 10;                            // 8 bucket-row pieces + 2 slot records
 
 struct Bwd {
   Ids ids;
@@ -353,13 +363,17 @@ struct Bwd {
   int act;
   const int32_t* counts;                       // (nu + ni) from the forward
   const int32_t* ranks;                        // (m + 1, 2)
-  float* gz;                                   // (2m, 64): buckets, user rows' slots first
-  float* aux;                                  // (2m, 4): {gz, partner id, row, -} per slot
+  float* gz;                                   // (2m + 1, 64): buckets, user rows' slots first, one spare slot
+  float* aux;                                  // (2m + 1, 4): {gz, partner id, row, -} per slot
   int32_t* offsets;                            // (nu + ni + 1): written by workgroup 0 for the later launches
   float* slabs;                                // (grid, kSlab)
   float* zero_a; int64_t zero_a_floats;        // cleared first: the segment sums (nu + ni, 128)
   float* zero_b; int64_t zero_b_floats;        // cleared first (nullable): the step's gradient buffer
 };
+
+__device__ __forceinline__ int sw1(int r) { return (r >> 1) & 7; }   // chunk swizzles of the 128 / 64 / 32-byte rows
+__device__ __forceinline__ int sw2(int r) { return (r >> 2) & 3; }
+__device__ __forceinline__ int sw3(int r) { return (r >> 3) & 1; }
 
 __global__ void __launch_bounds__(kThreads)
 ncfp_bwd_kernel(const Tower T, int64_t m, const Bwd B) {
@@ -367,17 +381,23 @@ ncfp_bwd_kernel(const Tower T, int64_t m, const Bwd B) {
   __shared__ __attribute__((aligned(16))) float s_hw[kHeadW + 4];
   __shared__ int s_scan[kWaves];
   float* s_wt = lds;
-  const int lane = threadIdx.x & 63, q = lane >> 4, lo = lane & 15, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, q = lane >> 4, lo = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* tA = lds + kWFloats + wave * kStripP;
   float* tB = tA + 2 * kTile;
+  float* stage = lds + kWFloats + kWaves * kStripP + wave * kBwdStage;
+  const uint32_t stage_addr = lds_addr(stage);
   const int64_t nrows = B.ids.nu + B.ids.ni;
-  int* s_off = reinterpret_cast<int*>(lds + kWFloats + kWaves * kStripP);   // nrows + 1 exclusive offsets
+  int* s_off = reinterpret_cast<int*>(lds + kWFloats + kWaves * (kStripP + kBwdStage));   // nrows + 1 exclusive offsets
   const int64_t groups = (m + 15) / 16;
   const int64_t wave0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * kThreads) >> 6;
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const float* pu = B.ptab;
   const float* pi = B.ptab + B.ids.nu * kN0;
   const uint32_t nu = (uint32_t)B.ids.nu, ni = (uint32_t)B.ids.ni;
+  int stamp = 0;
+  (void)stamp;
+  STAMP(1, stamp++);
 
   // ---- clear what this call accumulates into (both 16-byte aligned multiples of 4 floats)
   {
@@ -386,9 +406,8 @@ ncfp_bwd_kernel(const Tower T, int64_t m, const Bwd B) {
     if (B.zero_b)
       for (int64_t i = t0; i < B.zero_b_floats; i += step) stg4(B.zero_b + i, zero4);
   }
-  // ---- the fetch pipeline (see the note above ncfp_fwd_kernel): stage 1 = the ids of this lane's sample; stage 2 = every
-  // operand of the group, raw.  Sample-major "d": this lane's sample lo, units 4q + r; unit-major "t": unit lo,
-  // samples 4q + c -- their ids come out of the row's other lanes (ds_bpermute), not out of memory a second time.
+  // ---- the fetch pipeline (see the note above ncfp_fwd_kernel).  Stage 1: the ids of this lane's sample (sample lo of
+  // the group, the same in its four lanes).  Stage 2: the group's rows by LDS-DMA and the per-sample scalars.
   int64_t idu = 0, idi = 0;
   auto issue_ids = [&](int64_t g) {
     int64_t row = g * 16 + lo;
@@ -396,54 +415,58 @@ ncfp_bwd_kernel(const Tower T, int64_t m, const Bwd B) {
     idu = B.ids.uidx[row * B.ids.ustride];
     idi = B.ids.iidx[row * B.ids.istride];
   };
-  struct Raw {
+  struct Scal {
     float gp, pb;
     int ru, ri;                       // ranks of this lane's sample in its user / item row
     uint32_t u, i;                    // its ids, clamped (bad ids: row 0, no slot)
     bool ubad, ibad;
-    f32x4 y3d, y2d, y1d[2], pud[4], pid[4];
-    f32x4 y2t, y1t[2], put[4], pit[4];
   };
-  auto issue_rows = [&](int64_t g, Raw& r) {
+  auto issue_rows = [&](int64_t g, Scal& r) {
     int64_t rc = g * 16 + lo;
     rc = rc < m ? rc : m - 1;
     r.ubad = (uint64_t)idu >= nu;
     r.ibad = (uint64_t)idi >= ni;
     r.u = r.ubad ? 0u : (uint32_t)idu;
     r.i = r.ibad ? 0u : (uint32_t)idi;
+    // P_U / P_I: instruction k moves rows 4k .. 4k+3, lane l chunk (l % 16) ^ row of row 4k + l / 16
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = 4 * k + q;
+      const int src = (lane & 48) | row;                   // a lane of this quarter that holds sample row's ids
+      const uint32_t ur = (uint32_t)__shfl((int)r.u, src, 64), ir = (uint32_t)__shfl((int)r.i, src, 64);
+      const uint32_t col = 4u * (uint32_t)(lo ^ row);
+      dma16(pu + ur * 64u + col, stage_addr + (uint32_t)((kSgPU + 4 * k * 64) * 4));
+      dma16(pi + ir * 64u + col, stage_addr + (uint32_t)((kSgPI + 4 * k * 64) * 4));
+    }
+    {
+      // Y1 (32 floats a row): instruction k moves rows 8k .. 8k+7, lane l chunk (l % 8) ^ sw1(row) of row 8k + l / 8
+      const int64_t g16 = g * 16;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int row = 8 * k + (lane >> 3);
+        int64_t gr = g16 + row;
+        gr = gr < m ? gr : m - 1;
+        dma16(T.y[0] + gr * T.ldy[0] + 4 * ((lane & 7) ^ sw1(row)), stage_addr + (uint32_t)((kSgY1 + 8 * k * 32) * 4));
+      }
+      {   // Y2 (16 floats): lane l chunk (l % 4) ^ sw2(row) of row l / 4
+        const int row = lane >> 2;
+        int64_t gr = g16 + row;
+        gr = gr < m ? gr : m - 1;
+        dma16(T.y[1] + gr * T.ldy[1] + 4 * ((lane & 3) ^ sw2(row)), stage_addr + (uint32_t)(kSgY2 * 4));
+      }
+      {   // Y3 (8 floats): lane l chunk (l % 2) ^ sw3(row) of row (l / 2) % 16 (the upper half-wave repeats the lower)
+        const int row = (lane >> 1) & 15;
+        int64_t gr = g16 + row;
+        gr = gr < m ? gr : m - 1;
+        dma16(T.y[2] + gr * T.ldy[2] + 4 * ((lane & 1) ^ sw3(row)), stage_addr + (uint32_t)(kSgY3 * 4));
+      }
+    }
     r.gp = B.gprob[rc * B.ldgp];
     r.pb = B.prob[rc * B.ldp];
     r.ru = B.ranks[2 * rc];
     r.ri = B.ranks[2 * rc + 1];
-    r.y3d = ldg4(T.y[2] + rc * T.ldy[2] + 4 * (q & 1));     // (8 units: lanes q >= 2 re-read q - 2's and drop them)
-    r.y2d = ldg4(T.y[1] + rc * T.ldy[1] + 4 * q);
-#pragma unroll
-    for (int b = 0; b < 2; ++b) r.y1d[b] = ldg4(T.y[0] + rc * T.ldy[0] + 16 * b + 4 * q);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      r.pud[j] = ldg4(pu + r.u * kN0 + 16 * j + 4 * q);
-      r.pid[j] = ldg4(pi + r.i * kN0 + 16 * j + 4 * q);
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      int64_t rt = g * 16 + 4 * q + c;
-      rt = rt < m ? rt : m - 1;                             // (a clamped row meets a zero gradient)
-      const int src = (lane & 48) | (4 * q + c);           // the lane of this row that holds sample 4q + c
-      const uint32_t uc = (uint32_t)__shfl((int)r.u, src, 64), ic = (uint32_t)__shfl((int)r.i, src, 64);
-      r.y2t[c] = T.y[1][rt * T.ldy[1] + lo];
-#pragma unroll
-      for (int b = 0; b < 2; ++b) r.y1t[b][c] = T.y[0][rt * T.ldy[0] + 16 * b + lo];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        r.put[j][c] = pu[uc * kN0 + 16 * j + lo];
-        r.pit[j][c] = pi[ic * kN0 + 16 * j + lo];
-      }
-    }
   };
-  Raw rawA, rawB;
-  int stamp = 0;
-  (void)stamp;
-  STAMP(1, stamp++);
+  Scal sc;
   // ---- what a lane sums over every group it walks
   f32x4 dw0[2][4], dw1[2], dw2;                // dW blocks: register r = row 4q + r, column lo
   f32x4 sb0[2], sb1, sb2, hy = zero4;          // bias sums of this lane's sample: units 4q + r
@@ -476,7 +499,7 @@ ncfp_bwd_kernel(const Tower T, int64_t m, const Bwd B) {
         if (i < nrows) s_off[i] = v[e];
       }
     }
-    issue_rows(wave0, rawA);
+    issue_rows(wave0, sc);
     issue_ids(wave0 + nwaves);
     stage_transposed_store(s_wt, wv, wdst);
     if (threadIdx.x <= kHeadW) s_hw[threadIdx.x] = hw;
@@ -513,34 +536,46 @@ ncfp_bwd_kernel(const Tower T, int64_t m, const Bwd B) {
       for (int64_t i = threadIdx.x; i <= nrows; i += kThreads) B.offsets[i] = s_off[i];
   }
   STAMP(1, stamp++);   // scan done
+  // the first group's rows and scalars, the second group's ids (nothing else is in flight but workgroup 0's offsets)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("" : "+v"(idu), "+v"(idi), "+v"(sc.gp), "+v"(sc.pb), "+v"(sc.ru), "+v"(sc.ri));
 
-  // one group (see ncfp_fwd_kernel: unconditional stores, two named raw sets)
-  auto group = [&](int64_t g, Raw& raw, Raw& fill) {
+  for (int64_t g = wave0; g < groups; g += nwaves) {
     const bool live = g * 16 + lo < m;
-    // ---- raw operands of g -> operands (the one wait of the iteration; it also brings the ids of g + nwaves)
-    const float gp = live ? raw.gp : 0.0f;                   // a dead lane's gz is zero: it adds nothing anywhere
-    const float pb = raw.pb;
-    const f32x4 y3d = q < 2 ? raw.y3d : zero4, y2d = raw.y2d, y2t = raw.y2t;
-    f32x4 y1d[2], y1t[2], a0d[4], a0t[4];
+    // ---- staged rows of g -> operands
+    const float gp = live ? sc.gp : 0.0f;                    // a dead lane's gz is zero: it adds nothing anywhere
+    const float pb = sc.pb;
+    f32x4 y3d, y2d, y2t, y1d[2], y1t[2], a0d[4], a0t[4];
+    y3d = *reinterpret_cast<const f32x4*>(stage + kSgY3 + lo * 8 + 4 * ((q & 1) ^ sw3(lo)));
+    y3d = q < 2 ? y3d : zero4;
+    y2d = *reinterpret_cast<const f32x4*>(stage + kSgY2 + lo * 16 + 4 * (q ^ sw2(lo)));
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      y1d[b] = raw.y1d[b];
-      y1t[b] = raw.y1t[b];
-    }
+    for (int b = 0; b < 2; ++b) y1d[b] = *reinterpret_cast<const f32x4*>(stage + kSgY1 + lo * 32 + 4 * ((4 * b + q) ^ sw1(lo)));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const f32x4 zd = raw.pud[j] + raw.pid[j], zt = raw.put[j] + raw.pit[j];
+      const int at = lo * 64 + 4 * ((4 * j + q) ^ lo);
+      const f32x4 z = *reinterpret_cast<const f32x4*>(stage + kSgPU + at) + *reinterpret_cast<const f32x4*>(stage + kSgPI + at);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        a0d[j][r] = fmaxf(zd[r], 0.0f);
-        a0t[j][r] = fmaxf(zt[r], 0.0f);
+      for (int r = 0; r < 4; ++r) a0d[j][r] = fmaxf(z[r], 0.0f);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int row = 4 * q + c, ch = lo >> 2, w = lo & 3;
+      y2t[c] = stage[kSgY2 + row * 16 + 4 * (ch ^ sw2(row)) + w];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) y1t[b][c] = stage[kSgY1 + row * 32 + 4 * ((4 * b + ch) ^ sw1(row)) + w];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int at = row * 64 + 4 * ((4 * j + ch) ^ row) + w;
+        a0t[j][c] = fmaxf(stage[kSgPU + at] + stage[kSgPI + at], 0.0f);
       }
     }
-    const int uu = (int)raw.u, ii = (int)raw.i;
-    const int su = (live && !raw.ubad && raw.ru >= 0) ? raw.ru + s_off[uu] : -1;
-    const int si = (live && !raw.ibad && raw.ri >= 0) ? raw.ri + s_off[nu + ii] : -1;
-    STAMP(1, stamp++);   // operands converted (the wait)
-    issue_rows(g + nwaves, fill);
+    const int uu = (int)sc.u, ii = (int)sc.i;
+    const int su = (live && !sc.ubad && sc.ru >= 0) ? sc.ru + s_off[uu] : -1;
+    const int si = (live && !sc.ibad && sc.ri >= 0) ? sc.ri + s_off[nu + ii] : -1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the stage is read: it may be overwritten
+    STAMP(1, stamp++);   // operands read
+    issue_rows(g + nwaves, sc);
     issue_ids(g + 2 * nwaves);
     STAMP(1, stamp++);   // next group requested
     // ---- head: gz, the head's sums, the tower's (masked) gY
@@ -591,7 +626,7 @@ ncfp_bwd_kernel(const Tower T, int64_t m, const Bwd B) {
     {
       f32x4 tg[2];
       tiles_get<2>(tA, q, lo, tg);
-      // a sample without a slot (bad id, padding lane) writes to the spare row behind the buckets
+      // a sample without a slot (bad id, padding lane) writes to the spare slot behind the buckets
       float* du = B.gz + (int64_t)(su >= 0 ? su : 2 * m) * kN0 + 4 * q;
       float* di = B.gz + (int64_t)(si >= 0 ? si : 2 * m) * kN0 + 4 * q;
       dx_layer<0, 2>(s_wt, lane, gz1, w0, w1, [&](int j, const f32x4& d0, const f32x4& d1) {
@@ -613,19 +648,15 @@ ncfp_bwd_kernel(const Tower T, int64_t m, const Bwd B) {
             dw0[b][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(tg[b][c], a0t[j][c], dw0[b][j], 0, 0, 0);
     }
     STAMP(1, stamp++);   // layer 0 done
-  };
-  if (wave0 < groups) {
-    group(wave0, rawA, rawB);                        // peeled, as in ncfp_fwd_kernel
-    for (int64_t g = wave0 + nwaves; g < groups; g += 2 * nwaves) {
-      group(g, rawB, rawA);
-      if (g + nwaves >= groups) break;
-      group(g + nwaves, rawA, rawB);
-    }
+    // the next group's rows, scalars and its successor's ids are older than this group's kBwdStores stores
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kBwdStores) : "memory");
+    asm volatile("" : "+v"(idu), "+v"(idi), "+v"(sc.gp), "+v"(sc.pb), "+v"(sc.ru), "+v"(sc.ri));
   }
 
-  // ---- the workgroup's partial: every wave parks its sums (the weights and tiles are dead), then the slab is summed
-  // over the four copies on the way out
+  // ---- the workgroup's partial: every wave parks its sums (weights, tiles and stages are dead), the four copies are
+  // summed on the way out
   STAMP(1, stamp++);   // loop end
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (row fetches requested for a group past the end have landed)
   __syncthreads();
   {
     auto rsum = [&](const f32x4& v) {
@@ -650,30 +681,17 @@ ncfp_bwd_kernel(const Tower T, int64_t m, const Bwd B) {
         *reinterpret_cast<f32x4*>(small + 56 + 4 * q) = shy;       // sum gz * h: 8
       }
     }
-    if (lane == 0) small[64] = vc;
+    if (lane == 0) {
+      small[64] = vc;
+      small[65] = small[66] = small[67] = 0.0f;
+    }
   }
   __syncthreads();
   float* out = B.slabs + (int64_t)blockIdx.x * kSlab;
-  auto sum4 = [&](int at) { return (lds[at] + lds[kCopy + at]) + (lds[2 * kCopy + at] + lds[3 * kCopy + at]); };
-  // dW vectors: vector v of lane (q, lo), register r  ->  row 16b + 4q + r, column 16j + lo of its layer
-  for (int e = threadIdx.x; e < kVecs * 256; e += kThreads) {
-    const int v = e >> 8, ln = (e >> 2) & 63, r = e & 3, qq = ln >> 4, ll = ln & 15;
-    const int l = v < 8 ? 0 : v < 10 ? 1 : 2;
-    const int vv = v - (l == 0 ? 0 : l == 1 ? 8 : 10);
-    const int J = l == 0 ? 4 : l == 1 ? 2 : 1, K = l == 0 ? kK[0] : l == 1 ? kK[1] : kK[2];
-    const int bb = vv / J, jj = vv - bb * J;
-    const int rowi = 16 * bb + 4 * qq + r;
-    if (rowi < (l == 0 ? kN[0] : l == 1 ? kN[1] : kN[2]))
-      out[(l == 0 ? slab_w(0) : l == 1 ? slab_w(1) : slab_w(2)) + rowi * K + 16 * jj + ll] = sum4(e);
-  }
-  for (int i = threadIdx.x; i < kSmall; i += kThreads) {
-    const int at = kVecs * 256 + i;
-    int dst;
-    if (i < 32) dst = slab_w(0) + kN[0] * kK[0] + i;
-    else if (i < 48) dst = slab_w(1) + kN[1] * kK[1] + (i - 32);
-    else if (i < 56) dst = slab_w(2) + kN[2] * kK[2] + (i - 48);
-    else dst = kSlabHead + (i - 56);                               // 8 x (gz * h), then sum gz
-    out[dst] = sum4(at);
+  for (int i = threadIdx.x; i < kCopy / 4; i += kThreads) {
+    const f32x4 t = (*reinterpret_cast<const f32x4*>(lds + 4 * i) + *reinterpret_cast<const f32x4*>(lds + kCopy + 4 * i)) +
+                    (*reinterpret_cast<const f32x4*>(lds + 2 * kCopy + 4 * i) + *reinterpret_cast<const f32x4*>(lds + 3 * kCopy + 4 * i));
+    stg4(out + 4 * i, t);
   }
   STAMP(1, stamp++);   // slab written
 }
@@ -705,6 +723,20 @@ struct Seg {
   float* g_u; float* g_w; int64_t ld_g_w; float* g_b; float* g_b2;   // (+=), nullable
 };
 
+// float offset inside a slab of tower output e (e in the order [dW_l | db_l], l = 0..2)
+__device__ __forceinline__ int slab_raw_of(int e) {
+  int l = 0, r = e;
+#pragma unroll
+  for (int i = 0; i < kL; ++i)
+    if (e >= slab_w(i)) { l = i; r = e - slab_w(i); }
+  const int K = l == 0 ? kK[0] : l == 1 ? kK[1] : kK[2], N = l == 0 ? kN[0] : l == 1 ? kN[1] : kN[2];
+  if (r >= N * K) return kVecs * 256 + (l == 0 ? 0 : l == 1 ? 32 : 48) + (r - N * K);   // bias sums
+  const int row = r / K, col = r - row * K;
+  const int J = K / 16, v0 = l == 0 ? 0 : l == 1 ? 8 : 10;
+  const int v = v0 + (row >> 4) * J + (col >> 4);
+  return (v * 64 + ((row >> 2) & 3) * 16 + (col & 15)) * 4 + (row & 3);
+}
+
 __device__ __forceinline__ void slab_reduce_role(const Seg& A, int blk) {
   // outputs [32 blk, 32 blk + 32) of the kSlabHead tower sums: lane (o, pl) adds every 8th partial, 8 loads in flight
   __shared__ float s_part[kWaves][32];
@@ -712,7 +744,7 @@ __device__ __forceinline__ void slab_reduce_role(const Seg& A, int blk) {
   const int e = blk * 32 + o;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (e < kSlabHead) {
-    const float* src = A.slabs + e;
+    const float* src = A.slabs + slab_raw_of(e);
     int p = pl;
     for (; p + 7 * 8 < A.parts; p += 8 * 8) {
 #pragma unroll
@@ -726,7 +758,6 @@ __device__ __forceinline__ void slab_reduce_role(const Seg& A, int blk) {
   __syncthreads();
   if (threadIdx.x < 32 && e < kSlabHead) {
     const float total = (s_part[0][o] + s_part[1][o]) + (s_part[2][o] + s_part[3][o]);
-    // slab offset -> (layer, weight or bias element)
     int l = 0, r = e;
 #pragma unroll
     for (int i = 0; i < kL; ++i)
@@ -744,7 +775,7 @@ __device__ __forceinline__ void head_fold_role(const Seg& A) {
   const int col = threadIdx.x % 9, pl = threadIdx.x / 9;
   float acc = 0.0f;
   if (pl < 28) {
-    const float* src = A.slabs + kSlabHead + col;
+    const float* src = A.slabs + kVecs * 256 + 56 + col;
     float v[10];
 #pragma unroll
     for (int u = 0; u < 10; ++u) v[u] = 0.0f;
@@ -1099,7 +1130,7 @@ extern "C" int ctr_ncf_proj_bwd(const ctr_ncf_proj_t* d, const ctr_ncf_proj_grad
   const Ids ids{d->user_idx, d->user_stride, d->item_idx, d->item_stride, nu, ni};
   const Bwd B{ids, d->ptab, d->wfold, d->prob, d->ldprob, g->gprob, g->ldgprob, d->head_act, d->counts, d->ranks, gzb, aux,
               offs, slabs, stt, rows * 128, g->zero_buf, g->zero_buf ? g->zero_floats : 0};
-  const int64_t main_f = kWFloats + kWaves * kStripP + (rows + 1 + 3) / 4 * 4, copy_f = (int64_t)kWaves * kCopy;
+  const int64_t main_f = kWFloats + kWaves * (kStripP + kBwdStage) + (rows + 1 + 3) / 4 * 4, copy_f = (int64_t)kWaves * kCopy;
   const size_t lds_bytes = sizeof(float) * (size_t)(main_f > copy_f ? main_f : copy_f);
   CTR_REQUIRE(lds_bytes <= 150 * 1024, CTR_ELIMIT);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(ncfp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
