@@ -313,7 +313,9 @@ def gather_stage_leg(device, reps: int = 30):
 
 # kernel label (ops.py) -> kernel name in the rocprofv3 / PMC summaries under profiles/
 # label of an event-bracketed call -> the kernel name prefixes it may appear under in the PMC table (first match wins)
-KERNEL_NAMES = {"embed_fwd_fast": ("embed_ids_fast_kernel",), "mlp_fused_bwd": ("ncf16_bwd_kernel", "mlp_bwd_kernel"),
+KERNEL_NAMES = {"ncfp_prep": ("ncfp_prep_kernel",), "ncfp_fwd": ("ncfp_fwd_kernel",), "ncfp_bwd": ("ncfp_bwd_kernel",),
+                "ncfp_segsum": ("ncfp_segsum_kernel",), "ncfp_finish": ("ncfp_finish_kernel",),
+                "embed_fwd_fast": ("embed_ids_fast_kernel",), "mlp_fused_bwd": ("ncf16_bwd_kernel", "mlp_bwd_kernel"),
                 "mlp_fused_fwd": ("ncf16_fwd_kernel", "mlp_fwd_direct_kernel", "mlp_fwd_kernel"),
                 "embed_mlp_fused_fwd": ("ncf16_fwd_kernel",),
                 "embed_fwd": ("embed_rows_fast_kernel", "embed_fwd_kernel"),
@@ -323,6 +325,12 @@ KERNEL_NAMES = {"embed_fwd_fast": ("embed_ids_fast_kernel",), "mlp_fused_bwd": (
 
 # what one event-bracketed C-ABI call covers when it is more than one kernel
 LABEL_NOTES = {
+    "ncfp_fwd": "ncfp_fwd_kernel: ids -> rank atomics -> four cache-resident rows per sample by LDS-DMA -> 64-32-16-8 tower + "
+                "folded head (csrc/ncf_proj.hip); the first tower layer is a sum of two PROJECTED table rows (ncfp_prep)",
+    "ncfp_bwd": "ncfp_bwd_kernel: head + tower backward per sample; the one 64-float row a sample owes the first layer is "
+                "stored into its user's and its item's bucket (csrc/ncf_proj.hip)",
+    "ncfp_segsum": "ncfp_segsum_kernel: streaming sums over the buckets (+ the tower's slab reduction and the head fold's "
+                   "chain rule on workgroups of the same launch)",
     "embed_mlp_fused_fwd": "one ctr_embed_mlp_head_fwd call = ncf16_fwd_kernel<true>: ids -> table rows -> tower -> folded head",
     "mlp_fused_bwd": "one ctr_embed_mlp_head_bwd / ctr_mlp_head_bwd call = ncf16_bwd_kernel (mlp_bwd_kernel for other stacks) + "
                      "reduce_segments(_fold)_kernel (with the head fold's backward) + the gap between them; "

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (maps libamdhip64 first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTRHIP_LIB", os.path.join(_HERE, "libctrhip.so"))  # env override: A/B builds
-ABI_VERSION = 28
+ABI_VERSION = 29
 DIN_TRIPLE, DIN_PAIR, DIN_H = 0, 1, 2  # layouts of the DIN attention operand (include/ctrhip.h)
 
 CTR_MAX_FIELDS = 32
@@ -80,7 +80,7 @@ class NcfProj(C.Structure):
                 ("proj_k", C.c_int32), ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("head_act", C.c_int32),
                 ("prob", C.c_void_p), ("ldprob", C.c_int64), ("err_flag", C.c_void_p),
                 ("ptab", C.c_void_p), ("wfold", C.c_void_p), ("counts", C.c_void_p), ("ranks", C.c_void_p),
-                ("training", C.c_int32)]
+                ("training", C.c_int32), ("phases", C.c_int32)]
 
 
 class NcfProjGrad(C.Structure):
@@ -89,7 +89,7 @@ class NcfProjGrad(C.Structure):
                 ("g_mlp_user", C.c_void_p), ("g_mlp_item", C.c_void_p), ("g_gmf_user", C.c_void_p), ("g_gmf_item", C.c_void_p),
                 ("g_proj_w", C.c_void_p), ("ld_g_proj_w", C.c_int64), ("g_proj_b", C.c_void_p), ("g_head_w", C.c_void_p),
                 ("g_head_b", C.c_void_p), ("workspace", C.c_void_p), ("workspace_floats", C.c_int64),
-                ("zero_buf", C.c_void_p), ("zero_floats", C.c_int64)]
+                ("zero_buf", C.c_void_p), ("zero_floats", C.c_int64), ("phases", C.c_int32), ("reserved", C.c_int32)]
 
 
 class AdamTensor(C.Structure):

@@ -814,6 +814,9 @@ __device__ __forceinline__ void head_fold_role(const Seg& A) {
   if (threadIdx.x == 64 && A.g_b2) A.g_b2[0] += gc;
 }
 
+constexpr int kSegRange = 32;   // consecutive slots a lane group of sixteen owns
+constexpr int kSegBatch = 8;    // slots whose loads are in flight together
+
 __global__ void __launch_bounds__(kThreads)
 ncfp_segsum_kernel(const Seg A) {
   if ((int)blockIdx.x >= A.seg_blocks) {
@@ -821,53 +824,99 @@ ncfp_segsum_kernel(const Seg A) {
     else head_fold_role(A);
     return;
   }
+  // A lane group owns kSegRange consecutive slots and walks them kSegBatch at a time, software-pipelined: while batch k
+  // is summed, the rows of batch k + 1 (bucket row + the partner row its record names) and the records of batch k + 2
+  // are in flight.  A row whose whole bucket lies inside the range is STORED (nobody else adds to it); only the first and
+  // the last row of a range can continue in a neighbour's and are added atomically -- 2 per 64 slots instead of one per
+  // 12: the first version flushed every run with atomics and ran at the memory side's atomic rate (240 K 64-byte
+  // requests, TCC_EA0_ATOMIC), not at the rate the buckets can be read.
   __shared__ __attribute__((aligned(16))) float s_t[kThreads / 16][2][68];
   const int lane = threadIdx.x & 63, lo = lane & 15, grp = threadIdx.x >> 4;
   const int64_t total = A.offsets[A.nu + A.ni];
-  const int64_t s0 = ((int64_t)blockIdx.x * (kThreads / 16) + grp) * 16;
-  if (s0 >= total) return;
-  const int cnt = (int)((total - s0) < 16 ? (total - s0) : 16);
+  const int64_t s0 = ((int64_t)blockIdx.x * (kThreads / 16) + grp) * kSegRange;
+  const int64_t s1 = s0 + kSegRange < total ? s0 + kSegRange : total;   // (may be <= s0: nothing to do, but stay for the shuffles)
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 accs = zero4, acct = zero4;
   int cur = -1;
-  auto flush = [&](int v) {
-    float* t = &s_t[grp][0][0];
-    *reinterpret_cast<f32x4*>(t + 4 * lo) = accs;
-    *reinterpret_cast<f32x4*>(t + 68 + 4 * lo) = acct;
-    // (same lane group, same wave: the LDS pipe is in order, no barrier needed; the clobbers pin the order)
-    asm volatile("" ::: "memory");
+  bool cur_inside = false;   // the run being summed began inside this range (its row's bucket does not start earlier)
+  auto flush = [&](int v, bool complete) {
+    // a row whose whole bucket lies inside [s0, s1): plain stores; else atomics (transposed through LDS to 64-byte segments)
     float* dst = A.st + (int64_t)v * 128;
+    if (complete) {
+      stg4(dst + 4 * lo, accs);
+      stg4(dst + 64 + 4 * lo, acct);
+    } else {
+      float* t = &s_t[grp][0][0];
+      *reinterpret_cast<f32x4*>(t + 4 * lo) = accs;
+      *reinterpret_cast<f32x4*>(t + 68 + 4 * lo) = acct;
+      asm volatile("" ::: "memory");   // (same lane group, same wave: the LDS pipe is in order)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      ctr_atomic_add_global(dst + 16 * r + lo, t[16 * r + lo]);
-      ctr_atomic_add_global(dst + 64 + 16 * r + lo, t[68 + 16 * r + lo]);
-    }
-    asm volatile("" ::: "memory");
-  };
-  f32x4 ax[16], g[16], p[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) ax[k] = ldg4(A.aux + (s0 + (k < cnt ? k : cnt - 1)) * 4);
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int64_t s = s0 + (k < cnt ? k : cnt - 1);
-    const int pid = __float_as_int(ax[k][1]), v = __float_as_int(ax[k][2]);
-    g[k] = ldg4(A.gz + s * kN0 + 4 * lo);
-    p[k] = ldg4((v < A.nu ? A.gmf_i : A.gmf_u) + (int64_t)pid * kP + 4 * lo);
-  }
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    if (k < cnt) {
-      const int v = __float_as_int(ax[k][2]);
-      if (v != cur) {
-        if (cur >= 0) flush(cur);
-        cur = v;
-        accs = acct = zero4;
+      for (int r = 0; r < 4; ++r) {
+        ctr_atomic_add_global(dst + 16 * r + lo, t[16 * r + lo]);
+        ctr_atomic_add_global(dst + 64 + 16 * r + lo, t[68 + 16 * r + lo]);
       }
-      accs += g[k];
-      acct += ax[k][0] * p[k];
+      asm volatile("" ::: "memory");
+    }
+  };
+  const int64_t last = total > 0 ? total - 1 : 0;
+  // the rows of the slots just outside the range (requested with the first records): does the first / last run continue?
+  const f32x4 rec_before = ldg4(A.aux + (s0 > 0 ? (s0 - 1 < total ? s0 - 1 : last) : 0) * 4);
+  const f32x4 rec_after = ldg4(A.aux + (s1 < total ? s1 : last) * 4);
+  const int v_before = s0 > 0 ? __float_as_int(rec_before[2]) : -1;
+  const int v_after = s1 < total ? __float_as_int(rec_after[2]) : -1;
+  auto slot = [&](int64_t s) { return s < s1 ? s : (s1 > s0 ? s1 - 1 : last); };   // clamped: always a written slot
+  auto load_aux = [&](int64_t base, f32x4 (&ax)[kSegBatch]) {
+#pragma unroll
+    for (int k = 0; k < kSegBatch; ++k) ax[k] = ldg4(A.aux + slot(base + k) * 4);
+  };
+  auto load_rows = [&](int64_t base, const f32x4 (&ax)[kSegBatch], f32x4 (&g)[kSegBatch], f32x4 (&p)[kSegBatch]) {
+#pragma unroll
+    for (int k = 0; k < kSegBatch; ++k) {
+      const int pid = __float_as_int(ax[k][1]), v = __float_as_int(ax[k][2]);
+      g[k] = ldg4(A.gz + slot(base + k) * kN0 + 4 * lo);
+      p[k] = ldg4((v < A.nu ? A.gmf_i : A.gmf_u) + (int64_t)pid * kP + 4 * lo);
+    }
+  };
+  auto sum = [&](int64_t base, const f32x4 (&ax)[kSegBatch], const f32x4 (&g)[kSegBatch], const f32x4 (&p)[kSegBatch]) {
+#pragma unroll
+    for (int k = 0; k < kSegBatch; ++k) {
+      if (base + k < s1) {
+        const int v = __float_as_int(ax[k][2]);
+        if (v != cur) {
+          if (cur >= 0) flush(cur, cur_inside);       // it ended here, inside the range
+          cur_inside = base + k > s0 || v != v_before;
+          cur = v;
+          accs = acct = zero4;
+        }
+        accs += g[k];
+        acct += ax[k][0] * p[k];
+      }
+    }
+  };
+  if (total <= 0) return;
+  // batch k: records axA, rows (gA, pA); batch k + 1: records axB
+  f32x4 axA[kSegBatch], axB[kSegBatch], axC[kSegBatch], gA[kSegBatch], pA[kSegBatch], gB[kSegBatch], pB[kSegBatch];
+  load_aux(s0, axA);
+  load_rows(s0, axA, gA, pA);
+  load_aux(s0 + kSegBatch, axB);
+  constexpr int kPairs = kSegRange / (2 * kSegBatch);
+#pragma unroll 1
+  for (int it = 0; it < kPairs; ++it) {
+    const int64_t base = s0 + (int64_t)it * 2 * kSegBatch;
+    load_rows(base + kSegBatch, axB, gB, pB);          // rows of k + 1 (waits for its records)
+    load_aux(base + 2 * kSegBatch, axC);               // records of k + 2
+    sum(base, axA, gA, pA);                            // k (its rows were requested a batch ago)
+    load_rows(base + 2 * kSegBatch, axC, gA, pA);      // rows of k + 2
+    load_aux(base + 3 * kSegBatch, axA);               // records of k + 3
+    sum(base + kSegBatch, axB, gB, pB);                // k + 1
+#pragma unroll
+    for (int k = 0; k < kSegBatch; ++k) {              // next pair: k + 2 in (axA, gA, pA), records of k + 3 in axB
+      const f32x4 t = axA[k];
+      axA[k] = axC[k];
+      axB[k] = t;
     }
   }
-  if (cur >= 0) flush(cur);
+  if (cur >= 0) flush(cur, cur_inside && cur != v_after);
 }
 
 // ------------------------------------------------------------------ the products over the table rows
@@ -917,30 +966,46 @@ ncfp_finish_kernel(const Fin A) {
     // every operand is requested before any is consumed: they are independent of each other, and a load-use order was
     // eight dependent round trips on a handful of workgroups (12 us for 40 MFLOP)
     // ---- sample-major operands: this lane's row n, columns 16j + 4q ..
+    // (unconditional loads from a clamped row, zeroed afterwards: a load inside a conditional is a round trip of its own)
     f32x4 sd[4], td[4], gd[4], og[4], ot[4], wf[4];
+    const int64_t crow = live ? row : rows - 1;
+    const float* ogp = ggmf ? ggmf : gmf;      // (a missing gradient buffer: read something valid, the store is skipped)
+    const float* otp = gtab ? gtab : tab;
+    const float keep = live ? 1.0f : 0.0f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      sd[j] = live ? ldg4(st + row * 128 + 16 * j + 4 * q) : zero4;
-      td[j] = live ? ldg4(st + row * 128 + 64 + 16 * j + 4 * q) : zero4;
-      gd[j] = live ? ldg4(gmf + row * kP + 16 * j + 4 * q) : zero4;
-      og[j] = (live && ggmf) ? ldg4(ggmf + row * kP + 16 * j + 4 * q) : zero4;
-      ot[j] = (live && gtab) ? ldg4(gtab + row * kH + 16 * j + 4 * q) : zero4;
+      sd[j] = ldg4(st + crow * 128 + 16 * j + 4 * q);
+      td[j] = ldg4(st + crow * 128 + 64 + 16 * j + 4 * q);
+      gd[j] = ldg4(gmf + crow * kP + 16 * j + 4 * q);
+      og[j] = ldg4(ogp + crow * kP + 16 * j + 4 * q);
+      ot[j] = ldg4(otp + crow * kH + 16 * j + 4 * q);
       wf[j] = ldg4(A.wfold + 16 * j + 4 * q);
     }
     // ---- unit-major operands: unit / input n of rows 4q + c;  A operands of dMLP: W0[16j + 4q + c][coff + 16b + n]
     f32x4 stt[4], xt[4], wt[4][4];
+    float okc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int64_t r = r0 + 4 * q + c;
-      const bool ok = r < rows;
+      const int64_t rr = r < rows ? r : rows - 1;
+      okc[c] = r < rows ? 1.0f : 0.0f;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        stt[b][c] = ok ? st[r * 128 + 16 * b + n] : 0.0f;
-        xt[b][c] = ok ? tab[r * kH + 16 * b + n] : 0.0f;
+        stt[b][c] = st[rr * 128 + 16 * b + n];
+        xt[b][c] = tab[rr * kH + 16 * b + n];
 #pragma unroll
         for (int j = 0; j < 4; ++j) wt[j][b][c] = A.w0[(int64_t)(16 * j + 4 * q + c) * A.ldw0 + coff + 16 * b + n];
       }
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sd[j] *= keep;
+      td[j] *= keep;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) stt[b][c] *= okc[c];
     // dGMF[row] += wfold[:64] * T[row];   sum_rows GMF * T
     if (ggmf && live) {
 #pragma unroll
@@ -1063,8 +1128,12 @@ extern "C" int ctr_ncf_proj_workspace_floats(int64_t batch, int64_t num_users, i
   return CTR_OK;
 }
 
+// `phases`: 0 = the whole call; else a mask of its launches (a profiler brackets them one by one): forward 1 = projected
+// tables + head fold, 2 = the per-sample kernel; backward 1 = the per-sample kernel, 2 = segment sums + slab reduction +
+// head fold, 4 = the table-row products
 extern "C" int ctr_ncf_proj_fwd(const ctr_ncf_proj_t* d, void* stream) {
   CTR_REQUIRE(d && d->batch >= 0, CTR_EINVAL);
+  const int phases = d->phases ? d->phases : 3;
   if (!pattern_ok(d)) return CTR_ELIMIT;
   CTR_REQUIRE(d->prob && d->ldprob >= 1 && d->head_act >= CTR_ACT_NONE && d->head_act <= CTR_ACT_SIGMOID, CTR_EINVAL);
   CTR_REQUIRE(d->ld_proj_w >= d->proj_k, CTR_EINVAL);
@@ -1077,14 +1146,15 @@ extern "C" int ctr_ncf_proj_fwd(const ctr_ncf_proj_t* d, void* stream) {
   const int64_t pwaves = ctr_ceil_div(nu, 16) + ctr_ceil_div(ni, 16);
   const Prep P{d->mlp_user, d->mlp_item, d->layers[0].w, d->layers[0].k, d->layers[0].b, d->ptab, nu, ni,
                d->training ? d->counts : nullptr, nu + ni, d->head_w, d->proj_w, d->ld_proj_w, d->proj_b, d->head_b, d->wfold};
-  hipLaunchKernelGGL(ncfp_prep_kernel, dim3((unsigned)(ctr_ceil_div(pwaves, kWaves) + 1)), dim3(kThreads), 0, st, P);
+  if (phases & 1) hipLaunchKernelGGL(ncfp_prep_kernel, dim3((unsigned)(ctr_ceil_div(pwaves, kWaves) + 1)), dim3(kThreads), 0, st, P);
   rc = ctr_launch_status();
-  if (rc != CTR_OK || d->batch == 0) return rc;
+  if (rc != CTR_OK || d->batch == 0 || !(phases & 2)) return rc;
   const Fwd F{Ids{d->user_idx, d->user_stride, d->item_idx, d->item_stride, nu, ni}, d->ptab, d->gmf_user, d->gmf_item,
               d->wfold, d->prob, d->ldprob, d->head_act, d->err_flag, d->training ? d->counts : nullptr, d->ranks};
   const int64_t groups = ctr_ceil_div(d->batch, 16);
   int64_t grid = ctr_ceil_div(groups, kWaves);
-  static const int fwd_wgs = [] { const char* e = getenv("CTR_NCFP_FWD_WGS"); return e ? atoi(e) : 512; }();
+  // one workgroup per CU, every wave walks several groups: 25.6 us at batch 65536 against 28 us with two per CU
+  static const int fwd_wgs = [] { const char* e = getenv("CTR_NCFP_FWD_WGS"); return e ? atoi(e) : 256; }();
   if (grid > fwd_wgs) grid = fwd_wgs;
   static const int dbg = [] { const char* e = getenv("CTR_NCFP_DBG"); return e ? atoi(e) : 0; }();
   constexpr size_t fwd_lds = sizeof(float) * (kWFloats + kBFloats + 80 + kWaves * kFwdStage);
@@ -1136,25 +1206,34 @@ extern "C" int ctr_ncf_proj_bwd(const ctr_ncf_proj_t* d, const ctr_ncf_proj_grad
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(ncfp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds_bytes) != hipSuccess)
     return CTR_ELAUNCH;
-  hipLaunchKernelGGL(ncfp_bwd_kernel, dim3((unsigned)grid), dim3(kThreads), lds_bytes, st, T, m, B);
+  const int phases = g->phases ? g->phases : 7;
+  if (phases & 1) hipLaunchKernelGGL(ncfp_bwd_kernel, dim3((unsigned)grid), dim3(kThreads), lds_bytes, st, T, m, B);
   rc = ctr_launch_status();
   if (rc != CTR_OK) return rc;
   // segment sums over the buckets, and beside them (own workgroups) the tower's dW / db partials and the head fold's
   // chain rule (its GMF part arrives from ncfp_finish)
-  Seg S{gzb, aux, offs, d->gmf_user, d->gmf_item, nu, ni, stt, (int)ctr_ceil_div(2 * m, kThreads), (kSlabHead + 31) / 32,
+  Seg S{gzb, aux, offs, d->gmf_user, d->gmf_item, nu, ni, stt, (int)ctr_ceil_div(2 * m, (kThreads / 16) * kSegRange),
+        (kSlabHead + 31) / 32,
         slabs, (int)grid, {nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, d->head_w, d->proj_w, d->ld_proj_w,
         d->proj_b, g->g_head_w, g->g_proj_w, g->ld_g_proj_w, g->g_proj_b, g->g_head_b};
   for (int l = 0; l < kL; ++l) {
     S.gw[l] = g->layers[l + 1].gw;
     S.gb[l] = g->layers[l + 1].gb;
   }
-  hipLaunchKernelGGL(ncfp_segsum_kernel, dim3((unsigned)(S.seg_blocks + S.red_blocks + 1)), dim3(kThreads), 0, st, S);
+  {
+    // timing experiments (results are wrong): CTR_NCFP_SEG_DBG bit 0 drops the segment-sum workgroups, bit 1 the slab ones
+    static const int sdbg = [] { const char* e = getenv("CTR_NCFP_SEG_DBG"); return e ? atoi(e) : 0; }();
+    if (sdbg & 1) S.seg_blocks = 0;
+    if (sdbg & 2) S.red_blocks = 0;
+  }
+  if (phases & 2)
+    hipLaunchKernelGGL(ncfp_segsum_kernel, dim3((unsigned)(S.seg_blocks + S.red_blocks + 1)), dim3(kThreads), 0, st, S);
   rc = ctr_launch_status();
   if (rc != CTR_OK) return rc;
   const Fin N{stt, d->mlp_user, d->mlp_item, d->gmf_user, d->gmf_item, d->layers[0].w, d->layers[0].k, d->wfold, nu, ni,
               g->g_mlp_user, g->g_mlp_item, g->g_gmf_user, g->g_gmf_item, g->layers[0].gw, d->layers[0].k, g->layers[0].gb,
               g->g_head_w};
   const int64_t fwgs = ctr_ceil_div(ctr_ceil_div(nu, 16), kWaves) + ctr_ceil_div(ctr_ceil_div(ni, 16), kWaves);
-  hipLaunchKernelGGL(ncfp_finish_kernel, dim3((unsigned)fwgs), dim3(kThreads), 0, st, N);
+  if (phases & 4) hipLaunchKernelGGL(ncfp_finish_kernel, dim3((unsigned)fwgs), dim3(kThreads), 0, st, N);
   return ctr_launch_status();
 }

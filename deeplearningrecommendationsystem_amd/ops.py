@@ -673,22 +673,34 @@ class NcfProj:
                 tuple(proj[0].shape) == (64, 8) and all(layer.bias is not None for layer in hidden) and
                 rows <= _lib.CTR_NCF_PROJ_MAX_ROWS and batch >= 4096 and batch >= 4 * rows and 2 * batch < 2 ** 31)
 
-    def _meta(self, backward):
+    # algorithmic bytes / flops of the launches: per sample unless said otherwise
+    def _meta(self, which):
         m, rows = self.batch, self.nu + self.ni
         tower = 64 * 32 + 32 * 16 + 16 * 8
-        if not backward:
-            # ids, four 256-byte rows (cache-resident), saved activations + prob written; tower + head + row products
-            return lambda: (m * (16 + 4 * 256 + 4 * (32 + 16 + 8) + 4 + 8), 2 * m * (tower + 72 + 64) + 2 * rows * 64 * 64)
-        # activations + rows read again, one gz0 row written twice and read once per table, per-row products
-        return lambda: (m * (16 + 2 * 256 + 4 * (32 + 16 + 8) + 12 + 4 * (2 * 64 + 8) + 4 * 256),
-                        4 * m * tower + 2 * m * 72 + 2 * m * 2 * 64 + 3 * 2 * rows * 64 * 64)
+        return {
+            # (rows, 64) tables read, (rows, 64) projected rows written; one 64 x 64 product per row
+            "ncfp_prep": lambda: (rows * 512, 2 * rows * 64 * 64),
+            # ids, four 256-byte rows (cache-resident tables), saved activations + prob + ranks written; tower + head
+            "ncfp_fwd": lambda: (m * (16 + 4 * 256 + 4 * (32 + 16 + 8) + 4 + 8), 2 * m * (tower + 72 + 64)),
+            # ids, prob, gprob, ranks, two projected rows, saved activations read; gz0 row stored twice + two records
+            "ncfp_bwd": lambda: (m * (16 + 16 + 2 * 256 + 4 * (32 + 16 + 8) + 2 * 256 + 32), 4 * m * tower + 2 * m * 8),
+            # both buckets (row + record) and one partner row per slot read, (rows, 128) sums added
+            "ncfp_segsum": lambda: (2 * m * (256 + 16 + 256) + rows * 512, 2 * 2 * m * 64 * 2),
+            # sums + tables read, table gradients read-modify-written; three 64 x 64 products per row
+            "ncfp_finish": lambda: (rows * (512 + 512 + 4 * 256), 3 * 2 * rows * 64 * 64),
+        }[which]
 
     def forward(self) -> torch.Tensor:
         d = self._desc()
-        rc = _timed("ncf_proj_fwd", self._meta(False), _lib.load().ctr_ncf_proj_fwd, C.byref(d), _lib.stream_ptr())
+        fn = _lib.load().ctr_ncf_proj_fwd
+        if _profiler is None:
+            rc = fn(C.byref(d), _lib.stream_ptr())
+        else:   # one call per launch, so that each gets its own event pair
+            rc = 0
+            for phase, label in ((1, "ncfp_prep"), (2, "ncfp_fwd")):
+                d.phases = phase
+                rc = rc or _timed(label, self._meta(label), fn, C.byref(d), _lib.stream_ptr())
         if rc in _REFUSED:
-            if _profiler is not None and _profiler.records and _profiler.records[-1][0] == "ncf_proj_fwd":
-                _profiler.records.pop()
             return None
         _lib.check(rc, "ctr_ncf_proj_fwd")
         return self.prob
@@ -714,7 +726,14 @@ class NcfProj:
                                                                                       device=gmf_u.device)
         g.workspace, g.workspace_floats = ws.data_ptr(), ws.numel()
         g.zero_buf, g.zero_floats = _lib.ptr(zero), zero.numel() if zero is not None else 0
-        rc = _timed("ncf_proj_bwd", self._meta(True), _lib.load().ctr_ncf_proj_bwd, C.byref(d), C.byref(g), _lib.stream_ptr())
+        fn = _lib.load().ctr_ncf_proj_bwd
+        if _profiler is None:
+            rc = fn(C.byref(d), C.byref(g), _lib.stream_ptr())
+        else:
+            rc = 0
+            for phase, label in ((1, "ncfp_bwd"), (2, "ncfp_segsum"), (4, "ncfp_finish")):
+                g.phases = phase
+                rc = rc or _timed(label, self._meta(label), fn, C.byref(d), C.byref(g), _lib.stream_ptr())
         _lib.check(rc, "ctr_ncf_proj_bwd")
 
 

@@ -466,6 +466,8 @@ typedef struct ctr_ncf_proj {
   int32_t* err_flag;                              /* nullable */
   float* ptab; float* wfold; int32_t* counts; int32_t* ranks;
   int32_t training;
+  int32_t phases;                                 /* 0: the whole call; else a mask of its launches (forward: 1 projected tables
+                                                     + head fold, 2 per-sample kernel) -- for per-kernel timing */
 } ctr_ncf_proj_t;
 typedef struct ctr_ncf_proj_grad {
   const float* gprob; int64_t ldgprob;
@@ -474,6 +476,8 @@ typedef struct ctr_ncf_proj_grad {
   float* g_proj_w; int64_t ld_g_proj_w; float* g_proj_b; float* g_head_w; float* g_head_b;   /* (+=) */
   float* workspace; int64_t workspace_floats;     /* >= ctr_ncf_proj_workspace_floats(batch, users, items) */
   float* zero_buf; int64_t zero_floats;           /* nullable: cleared by the call's first launch (see ctr_embed_mlp_head_bwd) */
+  int32_t phases; int32_t reserved;               /* 0: the whole call; else a mask (1 per-sample kernel, 2 segment sums + slab
+                                                     reduction + head fold, 4 table-row products), issued in that order */
 } ctr_ncf_proj_grad_t;
 int ctr_ncf_proj_workspace_floats(int64_t batch, int64_t num_users, int64_t num_items, int64_t* floats /*host, out*/);
 int ctr_ncf_proj_fwd(const ctr_ncf_proj_t* d, void* stream);
