@@ -9,6 +9,8 @@
 // wave-instruction has 16 independent rows in flight.
 #include "ctr_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int kMaxUnits = 4096;   // units per sample the per-block LUT can hold
@@ -480,6 +482,98 @@ embed_ids_fast_bwd_kernel(const GradPtrs G, int nfields, int wshift, const int64
   }
 }
 
+// The same scatter with the rows a workgroup hits REPEATEDLY summed in LDS first (the backward half of "LDS staging of
+// hot rows").  fp32 atomics on one address are serialised by the memory side (~25-30 ns each, and they block the
+// requests queued behind them): under a Zipf law the hottest row of a 65536-sample batch is hit ~1900 times per field
+// and the launch took 170 us against 110 us for uniform ids.  Which rows are hot is not known in advance, so every
+// workgroup finds out for its own slice: a direct-mapped LDS cache of kHotSlots accumulator rows with admission on the
+// SECOND touch -- `seen[s]` remembers the last (field, row) that hashed to slot s and is overwritten freely; an item
+// that finds its own key there claims `tag[s]` (compare-and-swap from empty, never replaced) and from then on every
+// item of that row adds into the slot's LDS accumulator instead of issuing a global atomic; the accumulators are
+// flushed with one atomic row per slot at the end.  Rows seen once (uniform ids: practically all of them) take the
+// unchanged global path after two LDS reads and a write.  Workgroups walk CONTIGUOUS slices (so that the repeats of
+// a row meet in one cache) and there are fewer of them than in the plain kernel.
+constexpr uint32_t kHotEmpty = 0xffffffffu;
+
+template <int SLOTS_LOG2>
+__global__ void __launch_bounds__(1024)
+embed_ids_hot_bwd_kernel(const GradPtrs G, int nfields, int wshift, const int64_t* __restrict__ idx, uint32_t items,
+                         const float* __restrict__ gout, int64_t ldo, const CtrFastDiv div, uint32_t items_per_block) {
+  __shared__ float* s_grad[CTR_MAX_FIELDS];
+  __shared__ int64_t s_vocab[CTR_MAX_FIELDS];
+  constexpr int kHotSlots = 1 << SLOTS_LOG2;
+  __shared__ uint32_t s_seen[kHotSlots], s_tag[kHotSlots];
+  extern __shared__ float s_acc[];  // [kHotSlots][width]
+  const uint32_t width = 1u << wshift;
+  if (threadIdx.x < nfields) {
+    s_grad[threadIdx.x] = G.p[threadIdx.x];
+    s_vocab[threadIdx.x] = G.vocab[threadIdx.x];
+  }
+  for (int i = threadIdx.x; i < kHotSlots; i += blockDim.x) s_seen[i] = s_tag[i] = kHotEmpty;
+  for (int i = threadIdx.x; i < (kHotSlots << wshift); i += blockDim.x) s_acc[i] = 0.0f;
+  __syncthreads();
+  const uint32_t item0 = blockIdx.x * items_per_block;
+  const uint32_t item1 = item0 + items_per_block < items ? item0 + items_per_block : items;
+  const uint32_t g0 = item0 << wshift, g1 = item1 << wshift;   // (items << wshift < 2^32: checked on the host)
+  // kHotUnroll elements per thread and round: every load of a round is requested before any is used (two workgroups
+  // per CU fit beside the 64 KB of accumulators, so a round trip per element would be the whole kernel)
+  constexpr int kHotUnroll = 8;
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t gb = g0 + threadIdx.x; gb < g1; gb += blockDim.x * kHotUnroll) {
+    int64_t r[kHotUnroll];
+    float v[kHotUnroll];
+    uint32_t f[kHotUnroll];
+#pragma unroll
+    for (int k = 0; k < kHotUnroll; ++k) {
+      uint32_t g = gb + k * blockDim.x;
+      g = g < g1 ? g : g1 - 1;                     // (clamped: loaded, not used)
+      const uint32_t item = g >> wshift, e = g & (width - 1);
+      const uint32_t b = ctr_div(item, div);
+      f[k] = item - b * div.d;
+      r[k] = ctr_ldg(idx + item);
+      v[k] = ctr_ldg(gout + (int64_t)b * ldo + (f[k] << wshift) + e);
+    }
+#pragma unroll
+    for (int k = 0; k < kHotUnroll; ++k) {
+      const uint32_t g = gb + k * blockDim.x;
+      const uint32_t e = g & (width - 1);
+      float* dst = s_grad[f[k]];
+      const bool ok = g < g1 && dst != nullptr && r[k] >= 0 && r[k] < s_vocab[f[k]];   // frozen table / bad id: no gradient
+      const uint32_t key = (f[k] << 24) | (uint32_t)r[k];      // (every vocabulary < 2^24: checked on the host)
+      const uint32_t slot = (key * 2654435761u) >> (32 - SLOTS_LOG2);
+      // the first lane of an item (its `width` lanes are consecutive and share key) looks the row up for all of them
+      int hot = 0;
+      if (ok && e == 0) {
+        hot = s_tag[slot] == key;
+        if (!hot) {
+          if (s_seen[slot] == key) {
+            // second touch in this workgroup: claim the slot if nobody owns it
+            const uint32_t old = atomicCAS(&s_tag[slot], kHotEmpty, key);
+            hot = old == kHotEmpty || old == key;
+          } else {
+            s_seen[slot] = key;
+          }
+        }
+      }
+      // (width 16: an item is one DPP row, its first lane's answer is a row broadcast)
+      hot = wshift == 4 ? __builtin_amdgcn_update_dpp(0, hot, 0x150, 0xf, 0xf, false)
+                        : __shfl(hot, (int)(lane & ~(width - 1)), 64);
+      if (ok) {
+        if (hot) atomicAdd(s_acc + (slot << wshift) + e, v[k]);
+        else ctr_atomic_add_global(dst + (r[k] << wshift) + e, v[k]);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < ((uint32_t)kHotSlots << wshift); i += blockDim.x) {
+    const uint32_t key = s_tag[i >> wshift];
+    if (key == kHotEmpty) continue;
+    const float v = s_acc[i];
+    float* dst = s_grad[key >> 24];
+    ctr_atomic_add_global(dst + ((int64_t)(key & 0xffffffu) << wshift) + (i & (width - 1)), v);
+  }
+}
+
 bool try_fast_ids_bwd(const ctr_field_t* f, int n, int64_t batch, const float* gout, int64_t ldo, hipStream_t st,
                       int* rc) {
   const int w = f[0].width;
@@ -495,6 +589,35 @@ bool try_fast_ids_bwd(const ctr_field_t* f, int n, int64_t batch, const float* g
     G.vocab[i] = f[i].vocab;
   }
   const uint32_t items = (uint32_t)(batch * n);
+  // large stages: per-workgroup pre-reduction of repeated rows (embed_ids_hot_bwd_kernel); CTR_EMBED_HOT=0 keeps the plain
+  // scatter for A/B
+  static const int hot_mode = [] { const char* e = getenv("CTR_EMBED_HOT"); return e ? atoi(e) : 1; }();
+  bool small_vocab = true;
+  for (int i = 0; i < n; ++i) small_vocab = small_vocab && f[i].vocab < (1 << 24);
+  if (hot_mode && small_vocab && n <= 255 && w <= 32 && items >= 512u * 1024u) {
+    static const int hot_wgs = [] { const char* e = getenv("CTR_EMBED_HOT_WGS"); return e ? atoi(e) : 256; }();
+    static const int hot_slots = [] { const char* e = getenv("CTR_EMBED_HOT_SLOTS"); return e ? atoi(e) : 11; }();
+    static const int hot_threads = [] { const char* e = getenv("CTR_EMBED_HOT_THREADS"); return e ? atoi(e) : 1024; }();
+    const uint32_t per = (uint32_t)ctr_ceil_div(items, hot_wgs);
+    const unsigned grid = (unsigned)ctr_ceil_div(items, per);
+#define CTR_HOT_LAUNCH(L)                                                                                              \
+  do {                                                                                                                 \
+    const size_t lds = ((size_t)1 << L) * w * sizeof(float);                                                           \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(embed_ids_hot_bwd_kernel<L>),                                \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {                     \
+      *rc = CTR_ELAUNCH;                                                                                               \
+      return true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL(embed_ids_hot_bwd_kernel<L>, dim3(grid), dim3(hot_threads), lds, st, G, n, wshift, f[0].idx, items,  \
+                       gout, ldo, ctr_fastdiv((uint32_t)n), per);                                                      \
+  } while (0)
+    if (hot_slots == 9 || ((size_t)2048 * w * sizeof(float) > 140 * 1024 && hot_slots > 9)) CTR_HOT_LAUNCH(9);
+    else if (hot_slots == 10) CTR_HOT_LAUNCH(10);
+    else CTR_HOT_LAUNCH(11);
+#undef CTR_HOT_LAUNCH
+    *rc = ctr_launch_status();
+    return true;
+  }
   const int grid = ctr_stream_grid((int64_t)items * w, kBlock);
   hipLaunchKernelGGL(embed_ids_fast_bwd_kernel, dim3((unsigned)grid), dim3(kBlock), (size_t)n * w * sizeof(float), st, G, n,
                      wshift, f[0].idx, items, gout, ldo, ctr_fastdiv((uint32_t)n));

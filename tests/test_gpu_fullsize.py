@@ -102,6 +102,38 @@ def test_embedding_stage_26_fields_1e6_rows_batch_65536():
         _check_scatter(stage.tables[f].grad, idx[:, f], gout[:, f * dim:(f + 1) * dim], dim, [0, vocab - 1])
 
 
+def test_embedding_stage_scatter_under_a_zipf_law_hot_rows_summed_in_lds():
+    """the cfg3b scatter with Zipf ids (rank r with P(rank <= r) = log r / log V): the rows a workgroup hits repeatedly
+    are summed in an LDS cache before they reach the table gradient (embed_ids_hot_bwd_kernel) -- every row against
+    fp64 sums built on the host, for the hottest rows (thousands of contributions) and for rows hit once"""
+    from deeplearningrecommendationsystem_amd.model import EmbeddingStage
+    fields, vocab, dim, batch = 26, 1_000_000, 16, 65536
+    with torch.device(DEV):
+        stage = EmbeddingStage(fields, vocab, dim)
+    gen = torch.Generator().manual_seed(27)
+    u = torch.rand(batch, fields, generator=gen, dtype=torch.float64)
+    idx = (float(vocab) ** u - 1.0).long().clamp_(0, vocab - 1)
+    idx[0, :], idx[1, :] = vocab - 1, 0
+    out = stage(idx.to(DEV))
+    gout = torch.randn(batch, fields * dim, generator=gen)
+    out.backward(gout.to(DEV))
+    for f in (0, 7, 25):
+        ids, g = idx[:, f], gout[:, f * dim:(f + 1) * dim]
+        counts = torch.bincount(ids, minlength=8)
+        assert int(counts[1]) > 500, "the law must produce hot rows"
+        grad = stage.tables[f].grad
+        touched = torch.unique(ids)
+        nz = (grad != 0).any(dim=1).nonzero().flatten().cpu()
+        assert torch.equal(nz, touched), "rows with a gradient differ from the unique ids"
+        want = torch.zeros(vocab, dim, dtype=torch.float64)
+        want.index_add_(0, ids, g.double())
+        got = grad[touched.to(DEV)].cpu().double()
+        # a hot row sums thousands of N(0,1) terms in an order that changes from run to run
+        scale = counts[touched].double().sqrt().unsqueeze(1)
+        err = ((got - want[touched]).abs() / scale).max()
+        assert float(err) < 2e-5, float(err)
+
+
 @pytest.mark.parametrize("name,dim", [("din", 64), ("dien", 16)])
 def test_sequence_models_config5_full_size_forward_against_oracle_slice(name, dim):
     """BASELINE configs[4] on one GPU: item vocab 1e7, L = 100, batch 32768.  DIN/DIEN score every sample
