@@ -15,7 +15,7 @@ import torch  # noqa: F401  (maps libamdhip64 first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTRHIP_LIB", os.path.join(_HERE, "libctrhip.so"))  # env override: A/B builds
-ABI_VERSION = 29
+ABI_VERSION = 30
 DIN_TRIPLE, DIN_PAIR, DIN_H = 0, 1, 2  # layouts of the DIN attention operand (include/ctrhip.h)
 
 CTR_MAX_FIELDS = 32
@@ -161,6 +161,8 @@ SIGNATURES = {
     "ctr_embed_mlp_head_bwd": (_i, [C.POINTER(Field), _i, _l, C.POINTER(MlpLayer), _i, C.POINTER(MlpHeadGrad),
                                     C.POINTER(HeadFoldGrad), _p, _l, _p, _l, _p, _l, _p]),
     "ctr_mlp_head_bwd": (_i, [_p, _l, _l, C.POINTER(MlpLayer), _i, C.POINTER(MlpHeadGrad), _p, _l, _p, _l, _p]),
+    "ctr_rows_sum_act_fwd": (_i, [_p, _p, _l, _l, _p, _p, _l, _l, _l, _i, _i, _p, _l, _p, _p]),
+    "ctr_act_mask_bwd": (_i, [_p, _l, _p, _l, _l, _i, _i, _p]),
     "ctr_ncf_proj_workspace_floats": (_i, [_l, _l, _l, C.POINTER(C.c_int64)]),
     "ctr_ncf_proj_fwd": (_i, [C.POINTER(NcfProj), _p]),
     "ctr_ncf_proj_bwd": (_i, [C.POINTER(NcfProj), C.POINTER(NcfProjGrad), _p]),

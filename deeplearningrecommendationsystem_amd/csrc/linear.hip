@@ -528,7 +528,9 @@ extern "C" int ctr_linear_bwd(const float* x, int64_t ldx, const float* w, int64
     }
     splits = effective_splits(m, splits);
     const int64_t need = splits * (slab + n);
-    if (splits > 8 && workspace && workspace_floats >= need) {
+    // (a strided gW of more rows than the reduction pass has segments for: the atomic epilogue below takes any ldgw)
+    const bool seg_ok = ldgw == k || n + 1 <= CTR_MAX_SEGMENTS;
+    if (splits > 8 && workspace && workspace_floats >= need && seg_ok) {
       float* ws_b = workspace + splits * slab;
       // orientation: the 128-row side of the tile should be the longer of (n, k).  A funnel layer
       // (n = k/2, n < 128) fills half of a 128 x k tile as gZ^T X but all of a k x n tile as X^T gZ.
@@ -550,7 +552,6 @@ extern "C" int ctr_linear_bwd(const float* x, int64_t ldx, const float* w, int64
       if (ldgw == k) {
         segs.s[segs.n++] = CtrSegment{0, slab, gw};
       } else {
-        CTR_REQUIRE(n + 1 <= CTR_MAX_SEGMENTS, CTR_ELIMIT);
         for (int r = 0; r < n; ++r) segs.s[segs.n++] = CtrSegment{(int64_t)r * k, k, gw + r * ldgw};
       }
       rc = ctr_reduce_segments(workspace, (int)splits, slab, segs, st);

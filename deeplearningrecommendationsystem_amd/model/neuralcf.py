@@ -57,6 +57,95 @@ class _NeuralCFProjFunction(torch.autograd.Function):
         return (None, None, None, None) + tuple(zeros[id(p)] for p in params)
 
 
+class _NeuralCFRowsFunction(torch.autograd.Function):
+    """The same move for ANY tower (the reference script's NeuralCF(943, 1682, 256, [512, 256, 128, 64, 32]),
+    scripts/neuralcf.py:60): the first layer on the table rows, composed from library calls --
+        P_U = MLP_U W0[:, :h]^T, P_I = MLP_I W0[:, h:]^T + b0           two ctr_linear_fwd over U + I rows
+        a0  = relu(P_U[u] + P_I[i])                                      ctr_rows_sum_act_fwd
+        tower layers 1.., folded head, GMF product                       as in _NeuralCFFunction
+    backward: the gradient of a0, masked (ctr_act_mask_bwd), is the gradient of BOTH projected rows: ctr_embed_bwd sums
+    it by user and by item (S_U, S_I), and two ctr_linear_bwd over the table rows give dMLP = S W0half,
+    dW0half = S^T MLP, db0 = column sums.  Three quarters of the tower's matrix work leave the batch."""
+
+    @staticmethod
+    def forward(ctx, user_idx, item_idx, err_flag, n_hidden, gmf_u, gmf_i, mlp_u, mlp_i, *dense):
+        batch = user_idx.numel()
+        mf, half = gmf_u.shape[1], mlp_u.shape[1]
+        hidden = [Layer(dense[2 * k], dense[2 * k + 1], ACT_RELU) for k in range(n_hidden)]
+        proj_w, proj_b = dense[2 * n_hidden], dense[2 * n_hidden + 1]
+        head_w, head_b = dense[2 * n_hidden + 2], dense[2 * n_hidden + 3]
+        w0, b0 = hidden[0].weight, hidden[0].bias
+        n0, kh = w0.shape[0], proj_w.shape[1]
+        dev = gmf_u.device
+        p_u = ops.linear_fwd(mlp_u, w0[:, :half], None)
+        p_i = ops.linear_fwd(mlp_i, w0[:, half:], b0)
+        buf = torch.empty((batch, n0 + mf + kh), dtype=torch.float32, device=dev)   # [a0 | gmf | h]
+        ops.rows_sum_act_fwd(p_u, user_idx, p_i, item_idx, ACT_RELU, buf[:, :n0], err_flag)
+        ops.embed_fwd([FieldSpec(FIELD_PROD_I64, mf, n0, table=gmf_u, idx=user_idx, table2=gmf_i, idx2=item_idx)], None,
+                      batch, buf, err_flag)
+        wfold, cfold = ops.fold_head_fwd(head_w, mf, proj_w, proj_b, head_b)
+        head = ops.Head(buf[:, n0:n0 + mf], wfold, cfold, ACT_SIGMOID)
+        acts = ops.mlp_fwd(buf[:, :n0], hidden[1:], last_out=buf[:, n0 + mf:], head=head)
+        prob = head.out
+        ctx.n_hidden = n_hidden
+        ctx.save_for_backward(user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i, buf, prob, wfold, p_u, p_i, *acts[1:-1], *dense)
+        return prob
+
+    @staticmethod
+    def backward(ctx, gprob):
+        n_hidden = ctx.n_hidden
+        saved = ctx.saved_tensors
+        user_idx, item_idx, gmf_u, gmf_i, mlp_u, mlp_i, buf, prob, wfold, p_u, p_i = saved[:11]
+        nmid = n_hidden - 2
+        mids = list(saved[11:11 + nmid])
+        dense = saved[11 + nmid:]
+        batch = user_idx.numel()
+        mf, half = gmf_u.shape[1], mlp_u.shape[1]
+        hidden = [Layer(dense[2 * k], dense[2 * k + 1], ACT_RELU) for k in range(n_hidden)]
+        proj_w, proj_b = dense[2 * n_hidden], dense[2 * n_hidden + 1]
+        head_w, head_b = dense[2 * n_hidden + 2], dense[2 * n_hidden + 3]
+        w0, n0 = hidden[0].weight, hidden[0].weight.shape[0]
+        tables = (gmf_u, gmf_i, mlp_u, mlp_i)
+        zeros = ops.zero_grads(list(tables) + list(dense) + [wfold, head_b.new_empty(4), p_u, p_i])
+        gwfold, gcfold = zeros[id(wfold)], zeros[id(wfold)].new_zeros(1)
+        s_u, s_i = zeros[id(p_u)], zeros[id(p_i)]                 # the row sums of the first layer's gradient
+        gbuf = torch.empty_like(buf)
+        acts = [buf[:, :n0]] + mids + [buf[:, n0 + mf:]]
+        # the head as a single-unit layer on [gmf | h], then the tower down to a0
+        ops.linear_bwd(buf[:, n0:], wfold, prob, gprob.contiguous(), ACT_SIGMOID, gbuf[:, n0:], gwfold, gcfold)
+        layer_grads, _ = ops.mlp_bwd(acts, hidden[1:], gbuf[:, n0 + mf:], gbuf[:, :n0], zeros=zeros)
+        ops.act_mask_bwd(gbuf[:, :n0], buf[:, :n0], ACT_RELU)
+        ops.fold_head_bwd(head_w, mf, proj_w, proj_b, gwfold, gcfold, zeros[id(head_w)], zeros[id(proj_w)],
+                          zeros[id(proj_b)], zeros[id(head_b)])
+        specs = [FieldSpec(FIELD_ID_I64, n0, 0, table=p_u, idx=user_idx),
+                 FieldSpec(FIELD_ID_I64, n0, 0, table=p_i, idx=item_idx),
+                 FieldSpec(FIELD_PROD_I64, mf, n0, table=gmf_u, idx=user_idx, table2=gmf_i, idx2=item_idx)]
+        ops.embed_bwd(specs, None, batch, gbuf, zeros)
+        g_w0 = zeros[id(w0)]
+        ops.linear_bwd(mlp_u, w0[:, :half], None, s_u, ACT_NONE, zeros[id(mlp_u)], g_w0[:, :half], None, accumulate_gx=True)
+        ops.linear_bwd(mlp_i, w0[:, half:], None, s_i, ACT_NONE, zeros[id(mlp_i)], g_w0[:, half:], zeros[id(hidden[0].bias)],
+                       accumulate_gx=True)
+        out = [None, None, None, None] + [zeros[id(t)] for t in tables]
+        out += [g_w0, zeros[id(hidden[0].bias)]]
+        for gw, gb in layer_grads:
+            out += [gw, gb]
+        out += [zeros[id(proj_w)], zeros[id(proj_b)], zeros[id(head_w)], zeros[id(head_b)]]
+        return tuple(out)
+
+
+def _rows_path_ok(tables, hidden, batch) -> bool:
+    """the composed table-row path: a tower of at least two layers whose first layer takes cat(MLP_U[u], MLP_I[i]), row
+    counts far below the batch, widths the library's row kernels take"""
+    gmf_u, gmf_i, mlp_u, mlp_i = tables
+    rows = gmf_u.shape[0] + gmf_i.shape[0]
+    if len(hidden) < 2 or hidden[0].bias is None:
+        return False
+    n0, k0 = hidden[0].weight.shape
+    half = mlp_u.shape[1]
+    return (k0 == 2 * half and half % 4 == 0 and n0 % 4 == 0 and n0 <= 256 and gmf_u.shape[1] % 4 == 0 and
+            batch >= 4096 and batch >= 4 * rows)
+
+
 def _lib_error(msg):
     from .._lib import CtrHipError
     return CtrHipError(msg)
@@ -225,6 +314,9 @@ class NeuralCF(CtrModule):
                 tables, hidden, (self.linear.weight, self.linear.bias), user_indices.numel()) and not any(
                 getattr(t, "_ctr_sparse", None) is not None for t in tables):
             fn = _NeuralCFProjFunction
+        elif PROJECT_TABLES and user_indices.dim() == 1 and _rows_path_ok(tables, hidden, user_indices.numel()) and not any(
+                getattr(t, "_ctr_sparse", None) is not None for t in tables):
+            fn = _NeuralCFRowsFunction
         out = fn.apply(user_indices.contiguous(), item_indices.contiguous(), self._err_flag(w.device),
                        len(self.dnn_network), *tables, *dense)
         self._raise_if_bad_index()

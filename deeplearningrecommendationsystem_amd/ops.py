@@ -618,6 +618,28 @@ def mlp_bwd(acts: Sequence[torch.Tensor], layers: Sequence[Layer], gy: torch.Ten
     return grads, g
 
 
+def rows_sum_act_fwd(table_a, idx_a, table_b, idx_b, act: int, out, err_flag=None) -> torch.Tensor:
+    """out[b] = act(table_a[idx_a[b]] + table_b[idx_b[b]]) (ctr_rows_sum_act_fwd)"""
+    out = _mat(out, "out")
+    _lib.require_device(table_a, table_b, idx_a, idx_b)
+    batch, width = idx_a.numel(), table_a.shape[1]
+    rc = _timed("rows_sum_act_fwd", lambda: (batch * (16 + 12 * width), batch * width),
+                _lib.load().ctr_rows_sum_act_fwd, table_a.data_ptr(), idx_a.data_ptr(), idx_a.stride(0) if batch > 1 else 1,
+                table_a.shape[0], table_b.data_ptr(), idx_b.data_ptr(), idx_b.stride(0) if batch > 1 else 1, table_b.shape[0],
+                batch, width, act, out.data_ptr(), _ld(out), _lib.ptr(err_flag), _lib.stream_ptr())
+    _lib.check(rc, "ctr_rows_sum_act_fwd")
+    return out
+
+
+def act_mask_bwd(g, y, act: int) -> None:
+    """g *= act'(y) in place (ctr_act_mask_bwd)"""
+    g, y = _mat(g, "g"), _mat(y, "y")
+    m, n = g.shape
+    rc = _timed("act_mask_bwd", lambda: (12 * m * n, m * n), _lib.load().ctr_act_mask_bwd, g.data_ptr(), _ld(g),
+                y.data_ptr(), _ld(y), m, n, act, _lib.stream_ptr())
+    _lib.check(rc, "ctr_act_mask_bwd")
+
+
 # ---------------------------------------------------------------------------
 # NeuralCF with the first tower layer on the table rows (csrc/ncf_proj.hip)
 # ---------------------------------------------------------------------------

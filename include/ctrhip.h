@@ -433,6 +433,20 @@ int ctr_embed_mlp_head_bwd(const ctr_field_t* fields, int nfields, int64_t batch
                            float* gx, int64_t ldgx, float* workspace, int64_t workspace_floats,
                            float* zero_buf /*nullable*/, int64_t zero_floats, void* stream);
 /* ------------------------------------------------------------------------
+ * A first Linear on a concatenation of two gathered rows, with the layer applied to the TABLE ROWS (any width; the
+ * projected tables A = T_a W_a^T, B = T_b W_b^T + bias are two ctr_linear_fwd calls over the tables):
+ *   out[b, :] = act(A[idx_a[b], :] + B[idx_b[b], :])                (model/neuralcf.py:43-49 for any tower)
+ * An id outside its table reads row 0 and raises *err_flag.  Backward: ctr_act_mask_bwd turns the gradient of `out`
+ * into the gradient of the pre-activation in place (g *= act'(out)); ctr_embed_bwd with two id fields on the same
+ * gradient columns forms the row sums S_a, S_b; ctr_linear_bwd over the table rows turns them into the tables' and the
+ * layer's gradients (dT = S W, dW = S^T T). */
+int ctr_rows_sum_act_fwd(const float* table_a, const int64_t* idx_a, int64_t stride_a, int64_t vocab_a,
+                         const float* table_b, const int64_t* idx_b, int64_t stride_b, int64_t vocab_b,
+                         int64_t batch, int width, int act, float* out, int64_t ldo, int32_t* err_flag /*nullable*/,
+                         void* stream);
+int ctr_act_mask_bwd(float* g, int64_t ldg, const float* y, int64_t ldy, int64_t m, int n, int act, void* stream);
+
+/* ------------------------------------------------------------------------
  * NeuralCF (model/neuralcf.py:33-59) when the vocabularies are much smaller than the batch: the first tower layer and
  * its whole backward are moved from the samples to the table rows.  Linear(cat(MLP_U[u], MLP_I[i])) ==
  * (MLP_U W0a^T)[u] + (MLP_I W0b^T + b0)[i]: two products over num_users + num_items rows instead of one over the

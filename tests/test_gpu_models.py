@@ -510,6 +510,41 @@ def test_neuralcf_table_row_path_against_oracle_and_per_sample_path(nu, ni, batc
     _check_grads(grads, grads2)
 
 
+@pytest.mark.parametrize("shape,batch", [((943, 1682, 256, [512, 256, 128, 64, 32]), 65536),
+                                         ((943, 1682, 32, [64, 32, 16]), 12000), ((50, 70, 16, [96, 24, 8]), 5003)])
+def test_neuralcf_any_tower_table_row_path_against_oracle_and_per_sample_path(shape, batch):
+    """the reference script's own shape (scripts/neuralcf.py:60: NeuralCF(943, 1682, 256, [512, 256, 128, 64, 32])) at batch
+    65536, and two other towers: the composed table-row path (_NeuralCFRowsFunction: projected tables, row sums, products
+    over the table rows) against the CPU oracle and against the per-sample kernels"""
+    from deeplearningrecommendationsystem_amd import synth
+    from deeplearningrecommendationsystem_amd.model import NeuralCF
+    from deeplearningrecommendationsystem_amd.model import neuralcf as ncf_mod
+    nu, ni, mf, layers = shape
+    torch.manual_seed(17)
+    module = NeuralCF(nu, ni, mf, layers)
+    gen = synth.generator(batch)
+    u, i = synth.id_batch(batch, nu, ni, gen)
+    u[0], i[0], u[1], i[1] = 0, 0, nu - 1, ni - 1
+    y = synth.labels(batch, True, gen)
+    params = {k: v.detach().clone() for k, v in module.state_dict().items()}
+    prob_ref, loss_ref, grads_ref = orc.step("neuralcf", params, [u, i], y)
+    module = module.to(DEV)
+    calls = []
+    real = ncf_mod._NeuralCFRowsFunction.forward
+    try:
+        ncf_mod._NeuralCFRowsFunction.forward = staticmethod(lambda *a: (calls.append(1), real(*a))[1])
+        prob, loss, grads = _run(module, [u, i], y)
+    finally:
+        ncf_mod._NeuralCFRowsFunction.forward = staticmethod(real)
+    assert calls, "the composed table-row path did not run"
+    torch.testing.assert_close(prob, prob_ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(loss, loss_ref, rtol=1e-5, atol=1e-6)
+    _check_grads(grads, grads_ref)
+    prob2, loss2, grads2 = _ncf_step(module, u, i, y, False)
+    torch.testing.assert_close(prob, prob2, rtol=1e-5, atol=1e-6)
+    _check_grads(grads, grads2)
+
+
 def test_neuralcf_table_row_path_bad_ids_and_inference():
     """an id outside its table reads row 0 and raises the flag in the forward (nn.Embedding would raise IndexError:
     the gradients of such a step are not defined, they only have to stay finite and leave every row of the bad id's
