@@ -463,6 +463,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="enqueue every launch from Python instead of replaying a hipGraph")
     ap.add_argument("--sparse", action="store_true", help="opt-in sparse mode of the big tables' gradients (SURVEY 8f-3): "
                     "no dense zero-fill in backward, row-wise lazy Adam in full_step; NOT the reference's dense semantics")
+    ap.add_argument("--fresh-ids", action="store_true", help="with --shard: clone the input tensors every step (a new "
+                    "mini-batch object per step: the exchange plan is rebuilt every step)")
+    ap.add_argument("--capacity", type=float, default=0.0, help="with --shard: capacity factor of the capacity-bounded "
+                    "exchange layout (e.g. 1.25; 0 = exact layout with its one host read per fresh id tensor)")
     ap.add_argument("--shard", action="store_true", help="din / dien / ffm: row-shard the big id tables over the ranks "
                     "(all-to-all lookup, eager launches, global batch split over the ranks = strong scaling)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
@@ -492,6 +496,8 @@ def main():
     from deeplearningrecommendationsystem_amd.loss import BCELoss
     from deeplearningrecommendationsystem_amd.optim import Adam
 
+    if args.capacity:
+        os.environ["CTR_SHARD_CAPACITY"] = str(args.capacity)   # dist.ShardedEmbedding: capacity-bounded exchange layout
     if args.shard:
         args.no_graph = True  # the row exchanges are RCCL collectives between launches: eager (the plan of an id tensor
         #                       -- bucketing, id exchange, the one host read -- is built once and reused every step)
@@ -512,7 +518,9 @@ def main():
 
     def eager_step():
         model.zero_grad(set_to_none=True)
-        prob = model(*inputs)
+        # --fresh-ids: a data loader hands over NEW tensors every step -> no exchange plan can be reused
+        ins = [t.clone() for t in inputs] if args.fresh_ids else inputs
+        prob = model(*ins)
         loss = loss_fn(prob, y)
         loss.backward()
         if bucket is not None:
@@ -599,6 +607,8 @@ def main():
                        "parallelism": (f"dp{world}+rowshard{world}" if args.shard else f"dp{world}") if world > 1 or args.shard
                        else "single"},
             "loss": float(loss.item()), "launch": "eager" if args.no_graph else "hipGraph replay",
+            **({"exchange": {"layout": f"capacity-bounded x{args.capacity}" if args.capacity else "exact",
+                             "fresh_id_tensors_every_step": bool(args.fresh_ids)}} if args.shard else {}),
             "roofline": dict(entries[dominant], note=LABEL_NOTES.get(dominant) or entries[dominant].get("note"),
                              kernel_alone_rocprofv3=rocprof_kernel(args.workload, dominant, kernels[dominant]["flops"],
                                                                    kernels[dominant]["bytes"])),

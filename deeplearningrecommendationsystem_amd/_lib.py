@@ -15,7 +15,7 @@ import torch  # noqa: F401  (maps libamdhip64 first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTRHIP_LIB", os.path.join(_HERE, "libctrhip.so"))  # env override: A/B builds
-ABI_VERSION = 30
+ABI_VERSION = 31
 DIN_TRIPLE, DIN_PAIR, DIN_H = 0, 1, 2  # layouts of the DIN attention operand (include/ctrhip.h)
 
 CTR_MAX_FIELDS = 32
@@ -170,6 +170,10 @@ SIGNATURES = {
     "ctr_negative_sample": (_i, [_p, _l, _l, _l, _i, C.c_uint64, _p, _p, _p, _p]),
     "ctr_assemble_features": (_i, [_p, _p, _l, _p, _i, _l, _p, _i, _l, _p, _l, _p, _p]),
     "ctr_shard_bucket": (_i, [_p, _l, _i, _l, _p, _p, _p, _p, _p, _p]),
+    "ctr_shard_bucket_padded": (_i, [_p, _l, _i, _l, _l, _p, _p, _p, _p, _p, _p]),
+    "ctr_shard_recv_rows": (_i, [_p, _l, _l, _p, _p, _p, _p]),
+    "ctr_rows_zero": (_i, [_p, _l, _l, _i, _p, _l, _p]),
+    "ctr_topk_rows": (_i, [_p, _l, _l, _l, _l, _i, _p, _p, _p]),
     "ctr_fold_head_fwd": (_i, [_p, _i, _p, _l, _p, _p, _i, _i, _p, _p, _p]),
     "ctr_fold_head_bwd": (_i, [_p, _i, _p, _l, _p, _i, _i, _p, _p, _p, _p, _l, _p, _p, _p]),
     "ctr_bce_fwd": (_i, [_p, _l, _p, _l, _l, _p, _p, _l, _p, _p, _p]),

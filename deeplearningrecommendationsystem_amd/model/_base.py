@@ -7,7 +7,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from .. import _lib, sparse
+from .. import _lib, ops, sparse
 
 
 class CtrModule(nn.Module):
@@ -78,7 +78,7 @@ class CtrModule(nn.Module):
 
 
 def topk_rows(scores: torch.Tensor, k: int) -> np.ndarray:
-    return torch.topk(scores, k, dim=-1).indices.cpu().numpy()
+    return ops.topk_rows(scores, k).cpu().numpy()
 
 
 class _ModelFunction(torch.autograd.Function):
@@ -191,4 +191,4 @@ def _segment_topk(scores: torch.Tensor, counts: torch.Tensor, k: int) -> np.ndar
         valid = pos < counts.unsqueeze(1)
         grid = torch.full((n_seg, longest), float("-inf"), device=scores.device)
         grid[valid] = scores[(starts.unsqueeze(1) + pos)[valid]]
-    return torch.topk(grid, k, dim=1).indices.cpu().numpy()
+    return ops.topk_rows(grid, k).cpu().numpy()

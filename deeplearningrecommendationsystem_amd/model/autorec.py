@@ -55,8 +55,8 @@ class AutoRec(CtrModule):
 
     def recommendation(self, rating_matrix, k):
         with torch.no_grad():
-            return torch.topk(self.forward(rating_matrix), k, dim=1).indices.cpu().numpy()
+            return ops.topk_rows(self.forward(rating_matrix), k, dim=1).cpu().numpy()
 
     def i_recommendation(self, rating_matrix, k):
         with torch.no_grad():
-            return torch.topk(self.forward(rating_matrix), k, dim=0).indices.cpu().numpy()
+            return ops.topk_rows(self.forward(rating_matrix), k, dim=0).cpu().numpy()

@@ -122,7 +122,7 @@ class SequenceModel(CtrModule):
                     hist = torch.as_tensor(np.stack([np.asarray(hist_list[u], dtype=np.int64) for u in part]), device=dev)
                     hist = hist.repeat_interleave(num_items, 0)                     # (users * items, n)
                     scores = self.forward(hist, targets.repeat(len(part))).view(len(part), num_items)
-                    out[part] = torch.topk(scores, k, dim=1).indices.cpu().numpy()
+                    out[part] = ops.topk_rows(scores, k).cpu().numpy()
         return out
 
 

@@ -69,12 +69,17 @@ class FFM(FeatureModel):
             # (B, k) table indexed 0..B-1, and its gradient flows back through the exchange
             self._need_device(feature_vector, params[12])
             uid, iid = feature_vector[:, 0].long(), feature_vector[:, 1].long()
+            # every table's rows are requested first and waited for afterwards: table k+1's all-to-all runs on the
+            # collective stream while table k's rows are put back into batch order.  The ids are a temporary of the
+            # feature matrix: its identity / version key the exchange plan, which the two field-aware tables of an id
+            # column share (one id exchange per column)
+            flights = {}
             for k, name in enumerate(VECTORS):
                 if name in SHARDED:
-                    # the ids are a temporary of the feature matrix: its identity / version key the exchange plan,
-                    # which the two field-aware tables of an id column share (one id exchange per column)
                     user = name.startswith("userid")
-                    params[k] = getattr(self, name)(uid if user else iid, plan_key=(feature_vector, 0 if user else 1))
+                    flights[k] = getattr(self, name).start(uid if user else iid, plan_key=(feature_vector, 0 if user else 1))
+            for k, flight in flights.items():
+                params[k] = flight.wait()
         return self._run_model(feature_vector, params)
 
     def _specs(self, tables, dim):

@@ -333,4 +333,4 @@ class NeuralCF(CtrModule):
         with torch.no_grad():
             for lo in range(0, users.numel(), chunk):
                 scores[lo:lo + chunk] = self.forward(users[lo:lo + chunk], items[lo:lo + chunk]).view(-1)
-        return torch.topk(scores.view(num_users, num_items), num_items, dim=1).indices.cpu().numpy()
+        return ops.topk_rows(scores.view(num_users, num_items), num_items).cpu().numpy()

@@ -1197,3 +1197,25 @@ def gru_bwd(gi, w_hh, b_hh, hbuf, batch, length, dim, glast, dgi, dgh) -> None:
                 _lib.load().ctr_gru_bwd, gi.data_ptr(), _ld(gi), w_hh.data_ptr(), b_hh.data_ptr(), hbuf.data_ptr(),
                 batch, length, dim, glast.data_ptr(), _ld(glast), dgi.data_ptr(), dgh.data_ptr(), _lib.stream_ptr())
     _lib.check(rc, "ctr_gru_bwd")
+
+
+TOPK_MAX_K = 4096
+
+
+def topk_rows(scores: torch.Tensor, k: int, dim: int = -1) -> torch.Tensor:
+    """indices of the k best scores along ``dim`` of a 2-D float32 tensor, best first, ties by ascending index
+    (csrc/topk.hip) -- the ranking step of every ``recommendation()`` (reference: ``torch.topk(...)[1]``,
+    model/mf.py:28-35, neuralcf.py:61-72, pnn.py:133-143, din.py:55-66).  ``dim=0`` ranks columns (AutoRec's
+    item-based variant) and returns (k, cols) like torch.  k up to 4096."""
+    _lib.require_device(scores)
+    if scores.dim() != 2 or scores.dtype != torch.float32:
+        raise ValueError("topk_rows expects a 2-D float32 tensor")
+    along = dim % 2
+    rows, n = scores.shape[1 - along], scores.shape[along]
+    if not 1 <= k <= n:
+        raise RuntimeError(f"selected index k out of range: k = {k}, {n} candidates")
+    out = torch.empty((rows, k), dtype=torch.int64, device=scores.device)
+    rc = _lib.load().ctr_topk_rows(_lib.ptr(scores) if rows else None, scores.stride(1 - along), scores.stride(along), rows, n, k,
+                                   _lib.ptr(out) if rows else None, None, _lib.stream_ptr())
+    _lib.check(rc, "ctr_topk_rows")
+    return out if along == 1 else out.t()

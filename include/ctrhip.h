@@ -514,6 +514,34 @@ int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* l
  * ---------------------------------------------------------------------- */
 int ctr_shard_bucket(const int64_t* ids, int64_t n, int world, int64_t vocab, int64_t* counts, int64_t* cursor,
                      int32_t* send, int64_t* perm, int64_t* inv, void* stream);
+/* The capacity-bounded layout of the same bucketing: bucket w is slots [w*cap, (w+1)*cap) of `send` / `inv`
+ * (world*cap entries each) whatever the counts are, so the all-to-all has equal, host-known splits and a fresh id
+ * tensor needs no host read before its ids travel.  send[slot] = local row or -1 (unused); perm[i] = slot of id i;
+ * inv[slot] = i (an unused slot names some id of the batch: its row is masked out by the owner).  cursor: world + 1
+ * int64 of scratch (left holding the per-owner counts and the number of ids outside [0, vocab)).
+ * state (4 int64, written): {1 if a bucket received more than cap ids -- those ids are NOT placed, the caller must
+ * fall back to ctr_shard_bucket --, ids outside [0, vocab), n, -n}: MAX-all-reduced by the caller. */
+int ctr_shard_bucket_padded(const int64_t* ids, int64_t n, int world, int64_t vocab, int64_t cap, int64_t* cursor,
+                            int32_t* send, int64_t* perm, int64_t* inv, int64_t* state, void* stream);
+/* owner side of the padded exchange: rows[j] = recv[j] if it is a row of this shard, else j % local_rows (a harmless
+ * target: the slot's gradient row is multiplied by valid[j] = 0); valid[j] = 1.0 / 0.0; mark[j] = recv[j] or -1 (what
+ * ctr_rows_mark skips) */
+int ctr_shard_recv_rows(const int32_t* recv, int64_t slots, int64_t local_rows, int64_t* rows, float* valid,
+                        int64_t* mark, void* stream);
+/* table[idx[i]][0:dim] = 0 for i < n (idx outside [0, rows) skipped): clears the rows one step touched in a
+ * persistent dense shard-gradient buffer instead of zero-filling the whole shard */
+int ctr_rows_zero(float* table, int64_t ld, int64_t rows, int dim, const int64_t* idx, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Ranking step of recommendation() (model/mf.py:28-35, neuralcf.py:61-72, pnn.py:133-143, din.py:55-66: torch.topk
+ * over one user's candidate scores): for each of `rows` rows of n scores (element (r, j) at
+ * scores[r*row_stride + j*col_stride]) the indices of the k best, best first.  Order: score descending, NaN first
+ * (torch's convention), equal scores by ascending index (fixed, where torch leaves ties unspecified).
+ * idx_out (rows, k) int64; val_out (rows, k) nullable.  k <= 4096 (CTR_ELIMIT beyond), k <= n < 2^31.
+ * ---------------------------------------------------------------------- */
+#define CTR_TOPK_MAX_K 4096
+int ctr_topk_rows(const float* scores, int64_t row_stride, int64_t col_stride, int64_t rows, int64_t n, int k,
+                  int64_t* idx_out, float* val_out, void* stream);
 
 /* ------------------------------------------------------------------------
  * The host work either side of the step, on the device.

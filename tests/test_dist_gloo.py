@@ -26,12 +26,43 @@ class NumpyShardBackend:
         return counts, (r // world)[order].to(torch.int32), perm, order
 
     @staticmethod
+    def bucket_padded(ids, world, vocab, cap):
+        n = ids.numel()
+        bad = (ids < 0) | (ids >= vocab)
+        r = torch.where(bad, torch.zeros_like(ids), ids)
+        owner = r % world
+        send = torch.full((world * cap,), -1, dtype=torch.int32)
+        inv = torch.arange(world * cap) % max(n, 1)
+        perm = torch.empty(n, dtype=torch.int64)
+        over = 0
+        for w in range(world):
+            mine = torch.nonzero(owner == w).reshape(-1)
+            over |= int(mine.numel() > cap)
+            placed = mine[:cap]
+            slots = w * cap + torch.arange(placed.numel())
+            send[slots] = (r[placed] // world).to(torch.int32)
+            inv[slots] = placed
+            perm[placed] = slots
+            perm[mine[cap:]] = w * cap + cap - 1
+        return torch.tensor([over, int(bad.sum()), n, -n]), send, perm, inv
+
+    @staticmethod
+    def recv_rows(recv, local_rows):
+        ok = (recv >= 0) & (recv < local_rows)
+        rows = torch.where(ok, recv.long(), torch.arange(recv.numel()) % local_rows)
+        return rows, ok.float().view(-1, 1), torch.where(ok, recv.long(), torch.full_like(rows, -1))
+
+    @staticmethod
     def gather_rows(table, idx):
         return torch.from_numpy(table.detach().numpy()[idx.numpy()].copy())
 
     @staticmethod
     def scatter_add_rows(grad, idx, rows):
         np.add.at(grad.numpy(), idx.numpy(), rows.detach().numpy())
+
+    @staticmethod
+    def zero_rows(grad, idx):
+        grad.numpy()[idx.numpy()] = 0.0
 
 
 def _free_port():
@@ -113,6 +144,105 @@ def _sharded_worker(rank, world, port, vocab, dim, out):
         dist.destroy_process_group()
 
 
+def _full_grad(ids_list, gout_list, vocab, dim, rank, world):
+    """dense gradient of the FULL table summed over both ranks' batches -> this rank's shard of it"""
+    contrib = torch.zeros(vocab, dim)
+    for ids, gout in zip(ids_list, gout_list):
+        contrib.index_put_((ids.reshape(-1),), gout.reshape(-1, dim), accumulate=True)
+    dist.all_reduce(contrib)
+    return contrib[rank::world]
+
+
+def _fresh_batches_worker(rank, world, port, capacity, out):
+    """a training loop whose id tensor is a NEW tensor every step (what a data loader hands over): lookups and
+    gradients against the full table, step after step, with optimizer.zero_grad() in between"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from deeplearningrecommendationsystem_amd import dist as ctr_dist
+        vocab, dim = 53, 4
+        torch.manual_seed(0)
+        full = torch.randn(vocab, dim)
+        emb = ctr_dist.ShardedEmbedding(vocab, dim, backend=NumpyShardBackend(), average=False, capacity_factor=capacity)
+        emb.load_full_table(full)
+        other = ctr_dist.ShardedEmbedding(vocab, dim, backend=NumpyShardBackend(), average=False, capacity_factor=capacity)
+        other.load_full_table(2 * full)
+        g = torch.Generator().manual_seed(7 + rank)
+        buffers = set()
+        for step in range(6):
+            ids = torch.randint(0, vocab, (24, 2), generator=g)          # a new tensor object every step
+            emb.weight.grad = other.weight.grad = None                    # optimizer.zero_grad(set_to_none=True)
+            # two tables in flight together (table k+1's rows travel while table k's are put in order)
+            a, b = emb.start(ids), other.start(ids)
+            ra, rb = a.wait(), b.wait()
+            assert torch.equal(ra, full[ids]) and torch.equal(rb, 2 * full[ids]), f"step {step}: wrong rows"
+            ga, gb = torch.randn(ra.shape, generator=g), torch.randn(rb.shape, generator=g)
+            (ra * ga).sum().add((rb * gb).sum()).backward()
+            ref_a = _full_grad([ids], [ga], vocab, dim, rank, world)
+            ref_b = _full_grad([ids], [gb], vocab, dim, rank, world)
+            # (rows a previous step touched and this one does not must be back at zero)
+            torch.testing.assert_close(emb.weight.grad[:ref_a.shape[0]], ref_a, rtol=1e-6, atol=1e-6)
+            torch.testing.assert_close(other.weight.grad[:ref_b.shape[0]], ref_b, rtol=1e-6, atol=1e-6)
+            buffers.add(emb.weight.grad.data_ptr())
+        assert len(buffers) == 1, "the dense shard gradient must live in one persistent buffer"
+        assert emb.fallbacks == 0 and other.fallbacks == 0
+        # two lookups of one table in the same step accumulate (no clearing in between), as autograd would
+        emb.weight.grad = None
+        i1, i2 = torch.randint(0, vocab, (9,), generator=g), torch.randint(0, vocab, (9,), generator=g)
+        r1, r2 = emb(i1), emb(i2)
+        g1, g2 = torch.randn(r1.shape, generator=g), torch.randn(r2.shape, generator=g)
+        ((r1 * g1).sum() + (r2 * g2).sum()).backward()
+        ref = _full_grad([i1, i2], [g1, g2], vocab, dim, rank, world)
+        torch.testing.assert_close(emb.weight.grad[:ref.shape[0]], ref, rtol=1e-6, atol=1e-6)
+        # ... and a backward without zero_grad in between adds to what is there
+        r1 = emb(i1)
+        (r1 * g1).sum().backward()
+        ref2 = _full_grad([i1], [g1], vocab, dim, rank, world)
+        torch.testing.assert_close(emb.weight.grad[:ref.shape[0]], ref + ref2, rtol=1e-6, atol=1e-6)
+        if capacity is not None:
+            # every id owned by rank 0: the bucket overflows its capacity on every rank -> all ranks rebuild the
+            # plan in the exact layout; rows and gradients stay right
+            skew = torch.arange(0, 4000, 2).reshape(2000, 1) % vocab // world * world
+            emb.weight.grad = None
+            rows = emb(skew)
+            assert emb.fallbacks == 1 and torch.equal(rows, full[skew])
+            gs = torch.randn(rows.shape, generator=g)
+            (rows * gs).sum().backward()
+            ref = _full_grad([skew], [gs], vocab, dim, rank, world)        # (sums of ~75 rows each: summation order)
+            torch.testing.assert_close(emb.weight.grad[:ref.shape[0]], ref, rtol=1e-5, atol=1e-5)
+            # a different number of ids per rank (a ragged last batch): the wire must be sized without the ranks
+            # talking about it -- capacity_ids names the largest lookup
+            rag = ctr_dist.ShardedEmbedding(vocab, dim, backend=NumpyShardBackend(), average=False,
+                                            capacity_factor=capacity, capacity_ids=64)
+            rag.load_full_table(full)
+            for count in (5 + 3 * rank, 64 - 7 * rank, 0 if rank == 0 else 9):
+                ragged = torch.randint(0, vocab, (count,), generator=g)
+                rows = rag(ragged)
+                assert torch.equal(rows, full[ragged]) and rag.fallbacks == 0
+                rag.weight.grad = None
+                gr = torch.randn(rows.shape, generator=g)
+                (rows * gr).sum().backward()
+                ref = _full_grad([ragged], [gr], vocab, dim, rank, world)
+                torch.testing.assert_close(rag.weight.grad[:ref.shape[0]], ref, rtol=1e-6, atol=1e-6)
+            # an id outside the table on ONE rank raises on every rank, and the group stays usable
+            bad = torch.randint(0, vocab, (24,), generator=g)
+            if rank == 1:
+                bad[3] = vocab
+            try:
+                emb(bad)
+                raise AssertionError(f"rank {rank}: out-of-range id not reported in the capacity-bounded layout")
+            except IndexError:
+                pass
+            ok = torch.randint(0, vocab, (24,), generator=g)
+            assert torch.equal(emb(ok), full[ok])
+        out.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        out.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
 def _bucket_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -188,6 +318,12 @@ def test_sharded_embedding_two_ranks_matches_full_table():
 
 
 @pytest.mark.timeout(180)
+@pytest.mark.parametrize("capacity", [None, 1.5])
+def test_sharded_embedding_with_a_new_id_tensor_every_step(capacity):
+    _run(_fresh_batches_worker, capacity)
+
+
+@pytest.mark.timeout(180)
 def test_grad_bucket_all_reduce_mean_two_ranks():
     _run(_bucket_worker)
 
@@ -198,3 +334,9 @@ def test_numpy_backend_bucket_contract():
     assert counts.tolist() == [3, 3, 0] and send.dtype == torch.int32
     assert torch.equal(send[perm].long(), ids // 2)   # slot of element i holds its local row
     assert torch.equal(inv[perm], torch.arange(6))    # inv is the inverse permutation
+    state, send, perm, inv = NumpyShardBackend.bucket_padded(ids, 2, 10, 4)
+    assert state.tolist() == [0, 0, 6, -6] and send.numel() == 8 and (send == -1).sum() == 2
+    assert torch.equal(send[perm].long(), ids // 2) and torch.equal(inv[perm], torch.arange(6))
+    assert (perm[ids % 2 == 0] < 4).all() and (perm[ids % 2 == 1] >= 4).all()
+    state, _, perm, _ = NumpyShardBackend.bucket_padded(ids, 2, 10, 2)     # three ids per owner into two slots
+    assert state.tolist()[0] == 1 and int(perm.max()) < 4

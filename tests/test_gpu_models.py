@@ -235,7 +235,7 @@ def test_gradients_of_a_model_share_one_storage_for_the_data_parallel_all_reduce
     assert covered >= sum(p.numel() for p in model.parameters())
 
 
-def _sharded_sequence_worker(rank, world, port, kind, out):
+def _sharded_sequence_worker(rank, world, port, kind, capacity, out):
     # two ranks share the one GPU of the test box; gloo carries the exchange (staged through
     # the host, dist._host_staged) -- the protocol and every HIP step are the production ones
     import torch.distributed as dist
@@ -248,6 +248,8 @@ def _sharded_sequence_worker(rank, world, port, kind, out):
         from deeplearningrecommendationsystem_amd.model import DIEN, DIN
         cls = DIN if kind == "din" else DIEN
         vocab, dim, length, per_rank = 997, 16, 7, 96
+        if capacity:
+            os.environ["CTR_SHARD_CAPACITY"] = capacity      # dist.ShardedEmbedding: capacity-bounded exchange layout
         torch.manual_seed(3)
         full = cls(vocab, dim).to(DEV)                      # the unsharded model on the GLOBAL batch
         torch.manual_seed(4)
@@ -260,25 +262,30 @@ def _sharded_sequence_worker(rank, world, port, kind, out):
             else:
                 p.data.copy_(sd[name])
         gen = synth.generator(5)
-        hist, target = synth.hist_batch(world * per_rank, length, vocab, gen)
-        y = synth.labels(world * per_rank, True, gen)
-        hist, target, y = hist.to(DEV), target.to(DEV), y.to(DEV)
-        prob_full = full(hist, target)
-        BCELoss()(prob_full, y).backward()
-        mine = slice(rank * per_rank, (rank + 1) * per_rank)
-        prob = shard(hist[mine], target[mine])
-        BCELoss()(prob, y[mine]).backward()
-        GradBucket(shard.parameters()).all_reduce_mean()
-        torch.testing.assert_close(prob, prob_full[mine], rtol=1e-5, atol=1e-6)
+        table = shard.item_embedding if kind == "din" else shard.din.item_embedding
         ref = dict(full.named_parameters())
-        for name, p in shard.named_parameters():
-            want = ref[name].grad
-            if name.endswith("item_embedding.weight"):
-                want = want[rank::world]
-                got = p.grad[:want.shape[0]]
-            else:
-                got = p.grad
-            torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-6, msg=lambda m, n=name: f"{n}: {m}")
+        for step in range(3):                                # a NEW (hist, target) every step, zero_grad in between
+            hist, target = synth.hist_batch(world * per_rank, length, vocab, gen)
+            y = synth.labels(world * per_rank, True, gen)
+            hist, target, y = hist.to(DEV), target.to(DEV), y.to(DEV)
+            full.zero_grad(set_to_none=True)
+            shard.zero_grad(set_to_none=True)
+            prob_full = full(hist, target)
+            BCELoss()(prob_full, y).backward()
+            mine = slice(rank * per_rank, (rank + 1) * per_rank)
+            prob = shard(hist[mine], target[mine])
+            BCELoss()(prob, y[mine]).backward()
+            GradBucket(shard.parameters()).all_reduce_mean()
+            torch.testing.assert_close(prob, prob_full[mine], rtol=1e-5, atol=1e-6)
+            for name, p in shard.named_parameters():
+                want = ref[name].grad
+                if name.endswith("item_embedding.weight"):
+                    want = want[rank::world]
+                    got = p.grad[:want.shape[0]]
+                else:
+                    got = p.grad
+                torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-6, msg=lambda m, n=name: f"step {step} {n}: {m}")
+        assert table.fallbacks == 0
         out.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         import traceback
@@ -287,7 +294,7 @@ def _sharded_sequence_worker(rank, world, port, kind, out):
         dist.destroy_process_group()
 
 
-def _sharded_ffm_worker(rank, world, port, out):
+def _sharded_ffm_worker(rank, world, port, capacity, out):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -298,6 +305,8 @@ def _sharded_ffm_worker(rank, world, port, out):
         from deeplearningrecommendationsystem_amd.model import FFM
         from deeplearningrecommendationsystem_amd.model.ffm import SHARDED
         nu, ni, k, per_rank = 301, 407, 8, 160
+        if capacity:
+            os.environ["CTR_SHARD_CAPACITY"] = capacity
         torch.manual_seed(3)
         full = FFM(43, k, num_users=nu, num_items=ni).to(DEV)
         torch.manual_seed(4)
@@ -310,24 +319,37 @@ def _sharded_ffm_worker(rank, world, port, out):
             else:
                 p.data.copy_(sd[name])
         gen = synth.generator(9)
-        x = synth.feature_batch(world * per_rank, nu, ni, gen).to(DEV)
-        y = synth.labels(world * per_rank, True, gen).to(DEV)
-        prob_full = full(x)
-        BCELoss()(prob_full, y).backward()
-        mine = slice(rank * per_rank, (rank + 1) * per_rank)
-        prob = shard(x[mine])
-        BCELoss()(prob, y[mine]).backward()
-        GradBucket(shard.parameters()).all_reduce_mean()
-        torch.testing.assert_close(prob, prob_full[mine], rtol=1e-5, atol=1e-6)
         ref = dict(full.named_parameters())
-        for name, p in shard.named_parameters():
-            want = ref[name].grad
-            if name.split(".")[0] in SHARDED:
-                want = want[rank::world]
-                got = p.grad[:want.shape[0]]
-            else:
-                got = p.grad
-            torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-6, msg=lambda m, n=name: f"{n}: {m}")
+        for step in range(3):                                # a NEW feature matrix every step, zero_grad in between
+            x = synth.feature_batch(world * per_rank, nu, ni, gen).to(DEV)
+            y = synth.labels(world * per_rank, True, gen).to(DEV)
+            full.zero_grad(set_to_none=True)
+            shard.zero_grad(set_to_none=True)
+            prob_full = full(x)
+            BCELoss()(prob_full, y).backward()
+            mine = slice(rank * per_rank, (rank + 1) * per_rank)
+            prob = shard(x[mine])
+            BCELoss()(prob, y[mine]).backward()
+            GradBucket(shard.parameters()).all_reduce_mean()
+            torch.testing.assert_close(prob, prob_full[mine], rtol=1e-5, atol=1e-6)
+            for name, p in shard.named_parameters():
+                want = ref[name].grad
+                if name.split(".")[0] in SHARDED:
+                    want = want[rank::world]
+                    got = p.grad[:want.shape[0]]
+                else:
+                    got = p.grad
+                torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-6, msg=lambda m, n=name: f"step {step} {n}: {m}")
+        assert all(getattr(shard, n).fallbacks == 0 for n in SHARDED)
+        if capacity:
+            # every user id owned by rank 0: the capacity is exceeded, every rank falls back to the exact layout
+            big = 4000
+            x = synth.feature_batch(world * big, nu, ni, gen)
+            x[:, 0] = torch.floor(x[:, 0] / world) * world
+            x = x.to(DEV)
+            mine = slice(rank * big, (rank + 1) * big)
+            torch.testing.assert_close(shard(x[mine]), full(x)[mine], rtol=1e-5, atol=1e-6)
+            assert shard.userid_user.fallbacks == 1 and shard.itemid_user.fallbacks == 0
         out.put((rank, "ok"))
     except Exception:  # pragma: no cover
         import traceback
@@ -415,7 +437,8 @@ def test_row_sharded_ffm_config3_shape_two_ranks_against_the_oracle():
 
 
 @pytest.mark.timeout(300)
-def test_row_sharded_ffm_two_ranks_match_the_unsharded_model():
+@pytest.mark.parametrize("capacity", [None, "1.25"])
+def test_row_sharded_ffm_two_ranks_match_the_unsharded_model(capacity):
     # BASELINE configs[3]: the field-aware id tables row-sharded, lookups by all-to-all
     import socket
     import torch.multiprocessing as mp
@@ -424,7 +447,7 @@ def test_row_sharded_ffm_two_ranks_match_the_unsharded_model():
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=_sharded_ffm_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_sharded_ffm_worker, args=(r, 2, port, capacity, out)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -434,8 +457,8 @@ def test_row_sharded_ffm_two_ranks_match_the_unsharded_model():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("kind", ["din", "dien"])
-def test_row_sharded_item_table_two_ranks_match_the_unsharded_model(kind):
+@pytest.mark.parametrize("kind,capacity", [("din", None), ("dien", None), ("din", "1.25")])
+def test_row_sharded_item_table_two_ranks_match_the_unsharded_model(kind, capacity):
     # rows dealt round-robin to the ranks, ids / rows / row gradients exchanged
     # with all-to-all, dense layers replicated and their gradients averaged
     import socket
@@ -445,7 +468,7 @@ def test_row_sharded_item_table_two_ranks_match_the_unsharded_model(kind):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
-    procs = [ctx.Process(target=_sharded_sequence_worker, args=(r, 2, port, kind, out)) for r in range(2)]
+    procs = [ctx.Process(target=_sharded_sequence_worker, args=(r, 2, port, kind, capacity, out)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:

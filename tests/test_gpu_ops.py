@@ -908,7 +908,50 @@ def test_shard_bucket_kernel(n, world):
     assert torch.equal(owner_of_slot[perm], good % world)                # buckets are in rank order
 
 
-def test_sharded_embedding_single_rank_on_gpu():
+@pytest.mark.parametrize("n,world,cap", [(100000, 8, 12800), (100000, 8, 12000), (37, 2, 24), (1, 3, 8), (0, 4, 8),
+                                         (5000, 1, 5000)])
+def test_shard_bucket_padded_kernel(n, world, cap):
+    """the capacity-bounded layout: bucket w = slots [w*cap, (w+1)*cap), -1 in unused slots, overflow reported"""
+    from deeplearningrecommendationsystem_amd.dist import HipShardBackend
+    g = torch.Generator().manual_seed(n + world)
+    vocab = 1_000_000
+    ids = torch.randint(0, vocab, (n,), generator=g)
+    nbad = 0
+    if n >= 37:
+        ids[3], ids[11] = vocab + 5, -2
+        nbad = 2
+    state, send, perm, inv = (t.cpu() for t in HipShardBackend.bucket_padded(ids.to(DEV), world, vocab, cap))
+    good = torch.where((ids < 0) | (ids >= vocab), torch.zeros_like(ids), ids)
+    counts = torch.bincount(good % world, minlength=world)
+    assert state.tolist() == [int((counts > cap).any()), nbad, n, -n]
+    assert send.dtype == torch.int32 and send.numel() == world * cap and inv.numel() == world * cap
+    if n:
+        assert int(perm.min()) >= 0 and int(perm.max()) < world * cap            # in bounds even when overflowing
+        assert torch.equal(perm // cap, good % world)                         # every id sits in its owner's bucket
+        assert int(inv.min()) >= 0 and int(inv.max()) < n                     # unused slots name SOME id of the batch
+    for w in range(world):
+        bucket = send[w * cap:(w + 1) * cap]
+        used = min(int(counts[w]), cap)
+        assert int((bucket >= 0).sum()) == used and (bucket[used:] == -1).all()   # placed in arrival order, rest unused
+    if not state[0]:
+        assert torch.equal(send[perm].long(), good // world)                  # slot holds the local row
+        assert torch.equal(inv[perm], torch.arange(n))                        # inv is perm's inverse on the used slots
+    # the owner's side of it and the row clearing of the persistent gradient buffer
+    rows, valid, mark = (t.cpu() for t in HipShardBackend.recv_rows(send.to(DEV), 1000))
+    ok = (send >= 0) & (send < 1000)
+    assert torch.equal(valid.view(-1), ok.float()) and torch.equal(mark, torch.where(ok, send.long(), torch.full_like(rows, -1)))
+    assert torch.equal(rows[ok], send[ok].long()) and torch.equal(rows[~ok], (torch.arange(send.numel()) % 1000)[~ok])
+    for dim in (16, 7):
+        table = torch.randn(1000, dim, generator=g)
+        dev = table.to(DEV)
+        HipShardBackend.zero_rows(dev, rows.to(DEV)[: max(1, n // 3)])
+        want = table.clone()
+        want[rows[: max(1, n // 3)]] = 0.0
+        assert torch.equal(dev.cpu(), want)
+
+
+@pytest.mark.parametrize("capacity", [None, 1.25])
+def test_sharded_embedding_single_rank_on_gpu(capacity):
     import os
     import torch.distributed as dist
     from deeplearningrecommendationsystem_amd.dist import ShardedEmbedding
@@ -918,7 +961,7 @@ def test_sharded_embedding_single_rank_on_gpu():
     try:
         torch.manual_seed(0)
         full = torch.randn(5000, 16)
-        emb = ShardedEmbedding(5000, 16, device=DEV)
+        emb = ShardedEmbedding(5000, 16, device=DEV, capacity_factor=capacity)
         emb.load_full_table(full.to(DEV))
         ids = torch.randint(0, 5000, (300, 7))
         got = emb(ids.to(DEV))
@@ -927,8 +970,58 @@ def test_sharded_embedding_single_rank_on_gpu():
         got.backward(gout.to(DEV))
         ref = torch.zeros(5000, 16).index_put_((ids.reshape(-1),), gout.reshape(-1, 16), accumulate=True)
         torch.testing.assert_close(emb.weight.grad.cpu(), ref, rtol=1e-5, atol=1e-5)
+        # fresh id tensors step after step over RCCL: the gradient lives in one buffer, stale rows are cleared, the
+        # capacity-bounded layout never falls back (one rank owns every id: capacity >= n)
+        buf = emb.weight.grad.data_ptr()
+        for step in range(3):
+            emb.weight.grad = None
+            ids = torch.randint(0, 5000, (40 + step, 3))
+            got = emb(ids.to(DEV))
+            assert torch.equal(got.cpu(), full[ids])
+            gout = torch.randn(40 + step, 3, 16)
+            got.backward(gout.to(DEV))
+            ref = torch.zeros(5000, 16).index_put_((ids.reshape(-1),), gout.reshape(-1, 16), accumulate=True)
+            torch.testing.assert_close(emb.weight.grad.cpu(), ref, rtol=1e-5, atol=1e-5)
+            assert emb.weight.grad.data_ptr() == buf
+        assert emb.fallbacks == 0
+        with pytest.raises(IndexError):
+            emb(torch.tensor([1, 5000], device=DEV))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rows,n,k", [(943, 1682, 1682), (7, 1682, 10), (3, 1, 1), (5, 4096, 50), (4, 4097, 4096),
+                                      (6, 100000, 20), (2, 1000003, 100), (3, 20000, 1)])
+def test_topk_rows_ranks_like_torch_with_ties_by_index(rows, n, k):
+    """csrc/topk.hip against torch.topk on CPU (the reference's ranking call, model/mf.py:35): same scores position
+    by position; where scores tie, ascending index (torch leaves the order of ties open)"""
+    from deeplearningrecommendationsystem_amd import ops
+    g = torch.Generator().manual_seed(rows * 31 + n + k)
+    scores = torch.randn(rows, n, generator=g)
+    if n >= 1682:
+        scores[0] = torch.randint(0, 7, (n,), generator=g).float()          # heavy ties: only 7 distinct scores
+        scores[1, 5], scores[1, 900] = float("inf"), float("-inf")
+        scores[2 % rows, 17] = float("nan")                                  # NaN ranks first, as in torch
+        scores[-1] = 0.25                                                    # one value everywhere: index order
+    got = ops.topk_rows(scores.to(DEV), k).cpu()
+    assert got.shape == (rows, k) and got.dtype == torch.int64
+    # the exact expected order: stable sort by descending score, NaN first
+    key = torch.where(torch.isnan(scores), torch.full_like(scores, float("inf")), scores)
+    nan_first = torch.isnan(scores).double() * 1e30
+    want = torch.argsort(-(key.double().clamp(-1e300, 1e300).nan_to_num(posinf=1e29, neginf=-1e29) + nan_first), dim=1, stable=True)[:, :k]
+    assert torch.equal(got, want)
+    ref = torch.topk(scores, k, dim=1)
+    torch.testing.assert_close(torch.gather(scores, 1, got), ref.values, rtol=0, atol=0, equal_nan=True)
+    # a column-major view (AutoRec's item-based ranking: topk along dim 0) and a strided row view
+    view = scores.to(DEV).t().contiguous().t()                               # same values, column stride != 1
+    assert torch.equal(ops.topk_rows(view, k).cpu(), want)
+    kk = min(k, rows)
+    cols = ops.topk_rows(scores.to(DEV), kk, dim=0).cpu()
+    assert cols.shape == (kk, n)
+    torch.testing.assert_close(torch.gather(scores, 0, cols), torch.topk(scores, kk, dim=0).values, rtol=0, atol=0,
+                               equal_nan=True)
+    with pytest.raises(RuntimeError):
+        ops.topk_rows(scores.to(DEV), n + 1)
 
 
 def test_bce_loss_matches_torch():
