@@ -320,8 +320,11 @@ static int launch_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, 
                       int64_t ldr, float* y, int64_t ldy, int64_t m, int n, int k, int act, hipStream_t st,
                       int res_group = 1, uint32_t* mask = nullptr, int64_t ldmask = 0, const float* dot_w = nullptr,
                       const float* dot_b = nullptr, float* dot_out = nullptr, int64_t lddot = 0) {
-  const int nt = n <= 32 ? 1 : (n <= 64 ? 2 : 4);
+  int nt = n <= 32 ? 1 : (n <= 64 ? 2 : 4);
   const int64_t mtiles = ctr_ceil_div(m, kBM);
+  // few rows (a table of ~1000 rows instead of a batch): 128 x 128 tiles would leave most CUs without a workgroup
+  // (943 x 256: 16 of them) -- narrower column tiles re-read the few rows from L2 and fill the chip
+  while (nt > 1 && !dot_out && mtiles * ctr_ceil_div(n, 32 * nt) < 128) nt >>= 1;
   const int64_t ny = ctr_ceil_div(n, 32 * nt);
   int64_t gx = 256 * 3 / ny;  // rounded down: a workgroup beyond the resident 3 per CU would start a second round
   if (gx > mtiles) gx = mtiles;

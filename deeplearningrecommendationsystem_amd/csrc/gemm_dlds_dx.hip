@@ -406,8 +406,9 @@ struct DxEpilogue {
 static int launch_dx(const float* w, int64_t ldw, const float* y, int64_t ldy, const float* gy, int64_t ldgy, float* gx,
                      int64_t ldgx, int accumulate, int64_t m, int n, int k, int act, hipStream_t st,
                      const DxEpilogue& ep = DxEpilogue()) {
-  const int nt = k <= 32 ? 1 : (k <= 64 ? 2 : 4);
+  int nt = k <= 32 ? 1 : (k <= 64 ? 2 : 4);
   const int64_t mtiles = ctr_ceil_div(m, kBM);
+  while (nt > 1 && !ep.on && mtiles * ctr_ceil_div(k, 32 * nt) < 128) nt >>= 1;   // few rows: see gemm_dlds.hip
   const int64_t ny = ctr_ceil_div(k, 32 * nt);
   // rounded down: a workgroup beyond the resident ones would start a second round.  Two per CU with a Y tile in the
   // ring (72 KB of LDS); without one (48 KB, <= 144 registers) three fit

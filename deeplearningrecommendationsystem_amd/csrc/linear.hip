@@ -405,11 +405,13 @@ inline int effective_splits(int64_t K, int64_t splits) {
 template <int AMODE, int BMODE, class ASrc, class BSrc, class Epi>
 int launch(const ASrc& a, const BSrc& b, const Epi& e, int64_t M, int N, int64_t K, int splits, float* bias_grad,
            hipStream_t st, int64_t bias_slab_stride = 0, int bias_from_b = 0) {
-  const int nt = pick_nt(N);
+  int nt = pick_nt(N);
   const int64_t k_chunk = ctr_ceil_div(ctr_ceil_div(K, splits), kBK) * kBK;
   const int zs = (int)ctr_ceil_div(K, k_chunk);
   // as many workgroups as stay resident, each walking its share of the M tiles
   const int64_t mtiles = ctr_ceil_div(M, kBM);
+  // a handful of tiles for 256 CUs (products over ~1000 table rows): narrower column tiles instead
+  while (nt > 1 && mtiles * ctr_ceil_div(N, 32 * nt) * zs < 128) nt >>= 1;
   const int64_t others = ctr_ceil_div(N, 32 * nt) * zs;
   int64_t gx = ctr_ceil_div(256 * wg_per_cu(AMODE, BMODE), others);
   if (gx > mtiles) gx = mtiles;

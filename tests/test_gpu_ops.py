@@ -1168,7 +1168,9 @@ def test_linear_fwd_dot_forms_the_single_unit_layer_in_the_epilogue(ops, m, n, k
     y, out = ops.linear_fwd_dot(x.to(DEV), w.to(DEV), b.to(DEV), getattr(ops, act), u.to(DEV), c.to(DEV))
     torch.testing.assert_close(y.cpu(), want_y.float(), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(out.cpu(), want_o.float(), rtol=1e-5, atol=2e-5)
-    assert torch.equal(y.cpu(), ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), getattr(ops, act)).cpu())
+    # (the plain entry point picks narrower column tiles for a few rows: another summation order, same values to fp32)
+    torch.testing.assert_close(y.cpu(), ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), getattr(ops, act)).cpu(),
+                               rtol=1e-6, atol=1e-6)
 
 
 @pytest.mark.parametrize("batch,length,n,k,vocab", [(40, 100, 128, 64, 500), (7, 33, 64, 32, 50), (3, 130, 16, 128, 1000)])
