@@ -437,6 +437,16 @@ int launch(const ASrc& a, const BSrc& b, const Epi& e, int64_t M, int N, int64_t
 
 }  // namespace
 
+// Output widths a little above a multiple of the 128-column tile (641 = 5 * 128 + 1: Deep & Cross at emb 128): a sixth of
+// the tiles would compute padding.  The last 1..16 columns go to a launch of their own with a 32-column tile (it streams
+// the rows again: a long batch only).  Measured (65536 x 641 x 641, profiles/r03_tail_split.txt): forward 652 -> 578 us.
+// The same split of the INPUT-gradient's columns measured no gain (the 32-column tile kernel streams gZ at ~1.4 TB/s:
+// 610 -> 629 us) and a 33-column tail (161 = 128 + 33, Deep Crossing) on a 64-column tile neither: not done.
+static inline int tail_cols(int64_t m, int cols) {
+  const int r = cols % 128;
+  return (m >= 4096 && cols > 128 && r >= 1 && r <= 16) ? r : 0;
+}
+
 extern "C" int ctr_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
                               const float* residual, int64_t ldr, float* y, int64_t ldy, int64_t m, int n, int k,
                               int act, void* stream) {
@@ -445,6 +455,13 @@ extern "C" int ctr_linear_fwd(const float* x, int64_t ldx, const float* w, int64
   CTR_REQUIRE(x && w && y, CTR_EINVAL);
   CTR_REQUIRE(ldx >= k && ldw >= k && ldy >= n && (!residual || ldr >= n), CTR_EINVAL);
   CTR_REQUIRE(act >= CTR_ACT_NONE && act <= CTR_ACT_SIGMOID, CTR_EINVAL);
+  if (const int r = tail_cols(m, n)) {
+    const int n0 = n - r;
+    int rc = ctr_linear_fwd(x, ldx, w, ldw, bias, residual, ldr, y, ldy, m, n0, k, act, stream);
+    if (rc != CTR_OK) return rc;
+    return ctr_linear_fwd(x, ldx, w + (int64_t)n0 * ldw, ldw, bias ? bias + n0 : nullptr, residual ? residual + n0 : nullptr,
+                          ldr, y + n0, ldy, m, r, k, act, stream);
+  }
   if (n == 1 && ctr_n1_supported(k))
     return ctr_n1_fwd(x, ldx, w, bias, residual, ldr, y, ldy, m, k, act, (hipStream_t)stream);
   // K >= 16: operands stream global -> LDS directly (gemm_dlds.hip: 1.1-1.6x the tile kernel)
