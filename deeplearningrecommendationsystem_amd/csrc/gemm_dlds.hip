@@ -73,6 +73,42 @@ __device__ __forceinline__ void fetch(float* stage, const float* __restrict__ sr
   }
 }
 
+// The same fetch with the per-lane part of the address (row clamp, chunk swizzle, 64-bit row offset: ~12 vector
+// instructions per load) formed ONCE per tile: a 16-deep step that lies wholly inside K then costs one 64-bit add per
+// load.  (SQ counters of 65536 x 256 x 512: 79 non-MFMA vector + 50 scalar instructions per step and wave next to 32
+// MFMAs, against ~10 in hipBLASLt's kernel -- profiles/r03_gemm_counters.txt.)
+template <int ROWS>
+struct TileLanes {
+  static constexpr int kIters = (ROWS * 4 + kThreads - 1) / kThreads;
+  const float* p[kIters];
+};
+template <int ROWS>
+__device__ __forceinline__ void tile_lanes(TileLanes<ROWS>& t, const float* __restrict__ src, int64_t ld, int64_t row0,
+                                           int64_t rows_total, int lane, int wave) {
+  constexpr int kChunks = ROWS * 4;
+#pragma unroll
+  for (int i = 0; i < TileLanes<ROWS>::kIters; ++i) {
+    int q0 = 64 * wave + kThreads * i;
+    if (kChunks % kThreads != 0 && q0 >= kChunks) q0 -= kChunks;
+    const int q = q0 + lane;
+    const int row = q >> 2, c = (q & 3) ^ ((row >> 1) & 3);
+    int64_t gr = row0 + row;
+    gr = gr < rows_total ? gr : rows_total - 1;
+    t.p[i] = src + gr * ld + c * 4;
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void fetch_inside(float* stage, const TileLanes<ROWS>& t, int64_t k0, int wave) {
+  constexpr int kChunks = ROWS * 4;
+#pragma unroll
+  for (int i = 0; i < TileLanes<ROWS>::kIters; ++i) {
+    int q0 = 64 * wave + kThreads * i;
+    if (kChunks % kThreads != 0 && q0 >= kChunks) q0 -= kChunks;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(t.p[i] + k0),
+                                     (__attribute__((address_space(3))) void*)(stage + q0 * 4), 16, 0, 0);
+  }
+}
+
 // The operand fragments are read with ds_read_b128 written as asm: the compiler cannot tell which
 // stage an LDS-DMA load targets and would put s_waitcnt vmcnt(0) in front of every ordinary LDS read --
 // waiting for the loads issued a moment ago, i.e. no pipeline at all.  The waits are placed by hand
@@ -137,9 +173,23 @@ gemm_fwd_dlds_kernel(const DldsArgs a) {
       t += gridDim.x;
     }
   };
+  TileLanes<kBM> la;
+  TileLanes<BN> lb;
+  int64_t la_tile = -1;
+  tile_lanes<BN>(lb, a.w, a.ldw, j0, a.n, lane0, wave);     // the workgroup's weight rows never change
   auto issue = [&](int stage, int64_t t, int k) {
-    fetch<kBM>(s_a[stage], a.x, a.ldx, t * kBM, a.m, (int64_t)k * kBK, a.k, lane0, wave);
-    fetch<BN>(s_b[stage], a.w, a.ldw, j0, a.n, (int64_t)k * kBK, a.k, lane0, wave);
+    const int64_t k0 = (int64_t)k * kBK;
+    if (k0 + kBK <= a.k) {                                    // (uniform) the whole step lies inside K
+      if (t != la_tile) {
+        tile_lanes<kBM>(la, a.x, a.ldx, t * kBM, a.m, lane0, wave);
+        la_tile = t;
+      }
+      fetch_inside<kBM>(s_a[stage], la, k0, wave);
+      fetch_inside<BN>(s_b[stage], lb, k0, wave);
+    } else {
+      fetch<kBM>(s_a[stage], a.x, a.ldx, t * kBM, a.m, k0, a.k, lane0, wave);
+      fetch<BN>(s_b[stage], a.w, a.ldw, j0, a.n, k0, a.k, lane0, wave);
+    }
   };
   // slots g+1 and g+2 relative to the one being multiplied
   int64_t t1 = tile, t2;
