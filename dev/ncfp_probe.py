@@ -42,6 +42,21 @@ m = NeuralCF(943, 1682, 64, [128, 64, 32, 16, 8]).to(dev)
 gen = synth.generator(1)
 u, i = synth.id_batch(B, gen=gen)
 y = synth.labels(B, True, gen).to(dev)
+if os.environ.get("PROBE_IDS") == "regular":     # the pattern CTR_NCFP_DBG=8 computes, but LOADED from memory
+    u, i = (torch.arange(B) * 7) % 943, (torch.arange(B) * 13) % 1682
+elif os.environ.get("PROBE_IDS") == "sorted":    # random ids, sorted by user
+    order = torch.argsort(u, stable=True)
+    u, i = u[order], i[order]
+elif os.environ.get("PROBE_IDS") == "sorted_item":
+    order = torch.argsort(i, stable=True)
+    u, i = u[order], i[order]
+elif os.environ.get("PROBE_IDS") == "block16":   # one user per aligned block of 16 samples, blocks in random order
+    u = u[::16].repeat_interleave(16)
+elif os.environ.get("PROBE_IDS") == "block16_both":
+    u = u[::16].repeat_interleave(16)
+    i = i[::16].repeat_interleave(16)
+elif os.environ.get("PROBE_IDS") == "neighbours":   # sample b and b + 16384 (concurrent waves) share a user, no sharing inside a group
+    u = u[:16384].repeat(4)
 u, i = u.to(dev), i.to(dev)
 loss_fn = BCELoss()
 for _ in range(35):
