@@ -51,6 +51,8 @@ __device__ unsigned long long g_stamps[2][64];
 #define STAMP(k, i) do {} while (0)
 #endif
 
+constexpr int kCountStride = CTR_NCF_PROJ_COUNT_STRIDE;   // int32 between two rows' sample counters
+
 struct Ids {
   const int64_t* uidx; int64_t ustride;
   const int64_t* iidx; int64_t istride;
@@ -63,7 +65,6 @@ struct Prep {
   const float* w0; int64_t ldw0; const float* b0;   // layer 0: (64, 128), (64)
   float* ptab;                                 // (nu + ni, 64): P_U rows, then P_I rows
   int64_t nu, ni;
-  int32_t* counts; int64_t ncounts;            // nullable: zeroed (the forward's per-row sample counters)
   // head fold (ctr_fold_head_fwd's map for p = 64, n = 64, k = 8): wfold[0:72], wfold[72] = cfold
   const float* fold_u; const float* fold_w; int64_t fold_ldw; const float* fold_b; const float* fold_b2;
   float* wfold;
@@ -74,10 +75,6 @@ ncfp_prep_kernel(const Prep A) {
   const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
   const int64_t wave = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
   const int64_t ublocks = (A.nu + 15) / 16, iblocks = (A.ni + 15) / 16;
-  if (A.counts) {
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < A.ncounts; i += (int64_t)gridDim.x * kThreads)
-      A.counts[i] = 0;
-  }
   if (blockIdx.x == gridDim.x - 1) {
     // the folded head (ctr_fold_head_fwd's map): wfold[t < 64] = u[t]; wfold[64 + c] = sum_i W[i][c] u[64 + i] (column c
     // by the 32 threads t % 8 == c, two terms each, summed through LDS); wfold[72] = b . u[64:] + b2
@@ -144,8 +141,16 @@ struct Fwd {
   const float* wfold;                          // 72 weights + the bias
   float* out; int64_t ldout; int act;
   int32_t* err_flag;
-  int32_t* counts;                             // nullable (inference): per-row sample counters, users then items
-  int32_t* ranks;                              // (m + 1, 2): rank of a sample inside its user row / item row (-1: bad id)
+  // training (counts != nullptr): workgroups fwd_blocks .. gridDim - 1 of the SAME launch take every sample's rank
+  // inside its user row and its item row -- a returning atomic on counts (ALL ZERO at entry; the backward's last launch
+  // leaves them zero again) -- and write ranks (m, 2) for the backward's bucketing.  They share the CUs with the
+  // per-sample workgroups (two workgroups' worth of LDS fit a CU) and are done before those are.  Inside the per-sample
+  // loop the same atomics cost 12 of the forward's 25.8 us: same-LINE atomics are served one after the other at the
+  // memory side (~30 ns each) and a wave's memory operations retire in order (profiles/r03_rank_atomics.txt).  The unit
+  // of that serialisation is the line, not the address: with the 2625 counters packed (164 lines, 800 adds each) the
+  // atomics alone took 23 us; every counter therefore has a line to itself (kCountStride int32 apart): 6 us.
+  int32_t* counts; int32_t* ranks;
+  int fwd_blocks;
 };
 
 // How the loops of this file are written (what the first version got wrong, found with cycle stamps, an ablation and
@@ -167,7 +172,7 @@ struct Fwd {
 //
 // LDS-DMA and its waits are written by hand (the compiler cannot see which bytes an LDS-DMA writes and would wait for
 // every load in front of every LDS read).  Vector-memory operations retire in issue order; per group a wave issues
-//   [rank atomics: training] [kDma row fetches] [2 id loads] [kStores stores]
+//   [kDma row fetches] [2 id loads] [kStores stores]
 // so `vmcnt(kStores)` at the head of the next group means: its rows are staged and its successor's ids are here, while
 // this group's stores may still be on their way.
 __device__ __forceinline__ void dma16(const float* g, uint32_t lds_base) {
@@ -178,12 +183,23 @@ __device__ __forceinline__ uint32_t lds_addr(const float* p) {
   return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)p;
 }
 constexpr int kFwdStage = 4 * 16 * 64;   // floats per wave: P_U, P_I, GMF_U, GMF_I rows of sixteen samples
-constexpr int kFwdStores = 6;            // ranks, y1 x 2, y2, y3, prob
+constexpr int kFwdStores = 5;            // y1 x 2, y2, y3, prob
 
 // DBG != 0: timing experiments (dev/r03_ablate.sh; results are wrong): 2 no layers, 4 no y stores, 16 no prob store, 32 no row fetch
 template <int DBG>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 ncfp_fwd_kernel(const Tower T, int64_t m, const Fwd F) {
+  if ((int)blockIdx.x >= F.fwd_blocks) {
+    const int64_t nb = (int64_t)gridDim.x - F.fwd_blocks;
+    for (int64_t s0 = ((int64_t)blockIdx.x - F.fwd_blocks) * kThreads + threadIdx.x; s0 < m; s0 += nb * kThreads) {
+      const int64_t u = F.ids.uidx[s0 * F.ids.ustride], i = F.ids.iidx[s0 * F.ids.istride];
+      int ru = -1, ri = -1;                    // an id outside its table has no slot (the per-sample part raises the flag)
+      if ((uint64_t)u < (uint64_t)F.ids.nu) ru = atomicAdd(F.counts + u * kCountStride, 1);
+      if ((uint64_t)i < (uint64_t)F.ids.ni) ri = atomicAdd(F.counts + (F.ids.nu + i) * kCountStride, 1);
+      *reinterpret_cast<int2*>(F.ranks + 2 * s0) = make_int2(ru, ri);
+    }
+    return;
+  }
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* s_w = lds;                                   // kWFloats
   float* s_b = s_w + kWFloats;                        // kBFloats
@@ -193,7 +209,7 @@ ncfp_fwd_kernel(const Tower T, int64_t m, const Fwd F) {
   float* stage = s_hw + 80 + wave * kFwdStage;        // this wave's rows: [table][row][chunk ^ row] x 16 bytes
   const uint32_t stage_addr = lds_addr(stage);
   const int64_t groups = (m + 15) / 16;
-  const int64_t wave0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * kThreads) >> 6;
+  const int64_t wave0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6, nwaves = ((int64_t)F.fwd_blocks * kThreads) >> 6;
   const uint32_t nu = (uint32_t)F.ids.nu, ni = (uint32_t)F.ids.ni;
   const float* tabs[4] = {F.ptab, F.ptab + F.ids.nu * kN0, F.gmf_u, F.gmf_i};
   // stage 1: the two ids of this lane's sample (sample n of the group, the same in its four lanes)
@@ -209,18 +225,13 @@ ncfp_fwd_kernel(const Tower T, int64_t m, const Fwd F) {
       idi = F.ids.iidx[row * F.ids.istride];
     }
   };
-  // stage 2: rank atomics, then the four rows of every sample of the group by LDS-DMA.  Instruction k of a table moves
+  // stage 2: the four rows of every sample of the group by LDS-DMA.  Instruction k of a table moves
   // rows 4k .. 4k+3: lane l fetches chunk (l % 16) ^ row of row 4k + l / 16 into slot (row, l % 16).
-  auto issue_rows = [&](int64_t g, int& rank) {
+  auto issue_rows = [&](int64_t g) {
     const bool live = g * 16 + n < m;
     const bool ubad = (uint64_t)idu >= nu, ibad = (uint64_t)idi >= ni;
     const uint32_t u = ubad ? 0u : (uint32_t)idu, i = ibad ? 0u : (uint32_t)idi;
     if (live && (ubad || ibad) && F.err_flag) *F.err_flag = 1;
-    rank = -1;
-    if (F.counts && live) {   // rank of the sample inside its row: the slot the backward stores its gradient row to
-      if (q == 0 && !ubad) rank = atomicAdd(F.counts + u, 1);
-      if (q == 1 && !ibad) rank = atomicAdd(F.counts + nu + i, 1);
-    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int r = 4 * k + q;                          // the row this lane helps to fetch
@@ -242,7 +253,6 @@ ncfp_fwd_kernel(const Tower T, int64_t m, const Fwd F) {
   int stamp = 0;
   (void)stamp;
   STAMP(0, stamp++);
-  int rank_next = -1;
   issue_ids(wave0);
   {
     f32x4 wv[kFStagePer];
@@ -251,7 +261,7 @@ ncfp_fwd_kernel(const Tower T, int64_t m, const Fwd F) {
     stage_forward_load(T, wv, wdst, bv);
     float hw = 0.0f;
     if (threadIdx.x <= kHeadW) hw = F.wfold[threadIdx.x];
-    issue_rows(wave0, rank_next);      // (waits for the ids alone: loads return in order)
+    issue_rows(wave0);                 // (waits for the ids alone: loads return in order)
     issue_ids(wave0 + nwaves);
     stage_forward_store(s_w, s_b, wv, wdst, bv);
     if (threadIdx.x <= kHeadW) s_hw[threadIdx.x] = hw;
@@ -281,13 +291,10 @@ ncfp_fwd_kernel(const Tower T, int64_t m, const Fwd F) {
     for (int i = 0; i < 4; ++i)
       xe[i] = *reinterpret_cast<const f32x4*>(stage + (2 * 16 + n) * 64 + 4 * ((4 * q + i) ^ n)) *
               *reinterpret_cast<const f32x4*>(stage + (3 * 16 + n) * 64 + 4 * ((4 * q + i) ^ n));
-    const int rank = rank_next;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the stage is read: it may be overwritten
     STAMP(0, stamp++);
-    issue_rows(g + nwaves, rank_next);
+    issue_rows(g + nwaves);
     issue_ids(g + 2 * nwaves);
-    if constexpr (!(DBG & 64)) F.ranks[(q < 2 ? srow : m) * 2 + (q & 1)] = rank;
-    else asm volatile("" ::"v"(rank));
     STAMP(0, stamp++);
     f32x4 y1[2], y2[1], y3[1];
     if constexpr (DBG & 2) {
@@ -324,7 +331,7 @@ ncfp_fwd_kernel(const Tower T, int64_t m, const Fwd F) {
     else asm volatile("" ::"v"(dot));
     STAMP(0, stamp++);
     // the next group's rows and its successor's ids are older than this group's kFwdStores stores
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(((DBG & 4) ? ((DBG & 16) ? 1 : 2) : kFwdStores) - ((DBG & 64) ? 1 : 0)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DBG & 4) ? ((DBG & 16) ? 0 : 1) : kFwdStores) : "memory");
     asm volatile("" : "+v"(idu), "+v"(idi));
   }
 }
@@ -493,7 +500,7 @@ ncfp_bwd_kernel(const Tower T, int64_t m, const Bwd B) {
 #pragma unroll
       for (int e = 0; e < kCnt; ++e) {
         const int64_t i = base + e * kThreads + threadIdx.x;
-        v[e] = B.counts[i < nrows ? i : nrows - 1];
+        v[e] = B.counts[(i < nrows ? i : nrows - 1) * kCountStride];
       }
 #pragma unroll
       for (int e = 0; e < kCnt; ++e) {
@@ -934,6 +941,7 @@ struct Fin {
   float* g_mlp_u; float* g_mlp_i; float* g_gmf_u; float* g_gmf_i;   // (+=), nullable
   float* g_w0; int64_t ldgw0; float* g_b0;                           // (+=), nullable
   float* g_head;                                                     // g of linear2.weight[:64] (+=), nullable
+  int32_t* counts; int64_t ncounts;                                  // the step's sample counters: left all zero for the next forward
 };
 
 __global__ void __launch_bounds__(kThreads)
@@ -941,6 +949,8 @@ ncfp_finish_kernel(const Fin A) {
   __shared__ __attribute__((aligned(16))) float s_dw[2][16 * 256];
   __shared__ float s_sm[kWaves][2][64];
   const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15, wave = threadIdx.x >> 6;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < A.ncounts; i += (int64_t)gridDim.x * kThreads)
+    A.counts[i] = 0;    // (every reader -- the per-sample backward's scan -- is two launches back)
   const int64_t ublocks = (A.nu + 15) / 16, iblocks = (A.ni + 15) / 16;
   const int64_t uwgs = (ublocks + kWaves - 1) / kWaves;
   const bool user = (int64_t)blockIdx.x < uwgs;
@@ -1139,25 +1149,29 @@ extern "C" int ctr_ncf_proj_fwd(const ctr_ncf_proj_t* d, void* stream) {
   if (!pattern_ok(d)) return CTR_ELIMIT;
   CTR_REQUIRE(d->prob && d->ldprob >= 1 && d->head_act >= CTR_ACT_NONE && d->head_act <= CTR_ACT_SIGMOID, CTR_EINVAL);
   CTR_REQUIRE(d->ld_proj_w >= d->proj_k, CTR_EINVAL);
-  CTR_REQUIRE(d->ranks && (!d->training || d->counts), CTR_EINVAL);
+  CTR_REQUIRE(!d->training || (d->counts && d->ranks), CTR_EINVAL);
   Tower T;
   int rc = fill_tower(&T, d->layers, true);
   if (rc != CTR_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   const int64_t nu = d->num_users, ni = d->num_items;
   const int64_t pwaves = ctr_ceil_div(nu, 16) + ctr_ceil_div(ni, 16);
+  const Ids ids{d->user_idx, d->user_stride, d->item_idx, d->item_stride, nu, ni};
   const Prep P{d->mlp_user, d->mlp_item, d->layers[0].w, d->layers[0].k, d->layers[0].b, d->ptab, nu, ni,
-               d->training ? d->counts : nullptr, nu + ni, d->head_w, d->proj_w, d->ld_proj_w, d->proj_b, d->head_b, d->wfold};
+               d->head_w, d->proj_w, d->ld_proj_w, d->proj_b, d->head_b, d->wfold};
   if (phases & 1) hipLaunchKernelGGL(ncfp_prep_kernel, dim3((unsigned)(ctr_ceil_div(pwaves, kWaves) + 1)), dim3(kThreads), 0, st, P);
   rc = ctr_launch_status();
   if (rc != CTR_OK || d->batch == 0 || !(phases & 2)) return rc;
-  const Fwd F{Ids{d->user_idx, d->user_stride, d->item_idx, d->item_stride, nu, ni}, d->ptab, d->gmf_user, d->gmf_item,
-              d->wfold, d->prob, d->ldprob, d->head_act, d->err_flag, d->training ? d->counts : nullptr, d->ranks};
   const int64_t groups = ctr_ceil_div(d->batch, 16);
   int64_t grid = ctr_ceil_div(groups, kWaves);
   // one workgroup per CU, every wave walks several groups: 25.6 us at batch 65536 against 28 us with two per CU
   static const int fwd_wgs = [] { const char* e = getenv("CTR_NCFP_FWD_WGS"); return e ? atoi(e) : 256; }();
   if (grid > fwd_wgs) grid = fwd_wgs;
+  // rank workgroups (training): one sample per thread up to a chip's worth of them, behind the per-sample ones
+  int64_t rank_blocks = d->training ? ctr_ceil_div(d->batch, kThreads) : 0;
+  if (rank_blocks > 256) rank_blocks = 256;
+  const Fwd F{ids, d->ptab, d->gmf_user, d->gmf_item, d->wfold, d->prob, d->ldprob, d->head_act, d->err_flag,
+              d->training ? d->counts : nullptr, d->ranks, (int)grid};
   static const int dbg = [] { const char* e = getenv("CTR_NCFP_DBG"); return e ? atoi(e) : 0; }();
   constexpr size_t fwd_lds = sizeof(float) * (kWFloats + kBFloats + 80 + kWaves * kFwdStage);
   switch (dbg) {
@@ -1166,7 +1180,7 @@ extern "C" int ctr_ncf_proj_fwd(const ctr_ncf_proj_t* d, void* stream) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(ncfp_fwd_kernel<V>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                             (int)fwd_lds) != hipSuccess)                                                                 \
       return CTR_ELAUNCH;                                                                                                \
-    hipLaunchKernelGGL(ncfp_fwd_kernel<V>, dim3((unsigned)grid), dim3(kThreads), fwd_lds, st, T, d->batch, F);           \
+    hipLaunchKernelGGL(ncfp_fwd_kernel<V>, dim3((unsigned)(grid + rank_blocks)), dim3(kThreads), fwd_lds, st, T, d->batch, F); \
     break
     CTR_DBG_CASE(54); CTR_DBG_CASE(62); CTR_DBG_CASE(8);
     default: CTR_DBG_CASE(0);
@@ -1234,7 +1248,7 @@ extern "C" int ctr_ncf_proj_bwd(const ctr_ncf_proj_t* d, const ctr_ncf_proj_grad
   if (rc != CTR_OK) return rc;
   const Fin N{stt, d->mlp_user, d->mlp_item, d->gmf_user, d->gmf_item, d->layers[0].w, d->layers[0].k, d->wfold, nu, ni,
               g->g_mlp_user, g->g_mlp_item, g->g_gmf_user, g->g_gmf_item, g->layers[0].gw, d->layers[0].k, g->layers[0].gb,
-              g->g_head_w};
+              g->g_head_w, d->counts, rows * kCountStride};
   const int64_t fwgs = ctr_ceil_div(ctr_ceil_div(nu, 16), kWaves) + ctr_ceil_div(ctr_ceil_div(ni, 16), kWaves);
   if (phases & 4) hipLaunchKernelGGL(ncfp_finish_kernel, dim3((unsigned)fwgs), dim3(kThreads), 0, st, N);
   return ctr_launch_status();

@@ -33,11 +33,15 @@ class _NeuralCFProjFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, user_idx, item_idx, err_flag, n_hidden, gmf_u, gmf_i, mlp_u, mlp_i, *dense):
+        n_hidden, grad_on, counts = n_hidden                 # (the caller's grad mode: it is off in here; the model's counters)
         hidden = [Layer(dense[2 * k], dense[2 * k + 1], ACT_RELU) for k in range(n_hidden)]
         proj = (dense[2 * n_hidden], dense[2 * n_hidden + 1])
         head = (dense[2 * n_hidden + 2], dense[2 * n_hidden + 3])
-        training = any(ctx.needs_input_grad[4:])
-        run = ops.NcfProj(user_idx, item_idx, (gmf_u, gmf_i, mlp_u, mlp_i), hidden, proj, head, err_flag, training)
+        # needs_input_grad is True for parameters under torch.no_grad() too; without a graph there will be no backward, and
+        # the forward then takes no ranks (the backward's bucketing needs them; they are returning atomics:
+        # profiles/r03_rank_atomics.txt)
+        training = grad_on and any(ctx.needs_input_grad[4:])
+        run = ops.NcfProj(user_idx, item_idx, (gmf_u, gmf_i, mlp_u, mlp_i), hidden, proj, head, err_flag, training, counts)
         prob = run.forward()
         if prob is None:
             raise _lib_error("ctr_ncf_proj_fwd refused a shape NcfProj.supported() accepted")
@@ -317,8 +321,12 @@ class NeuralCF(CtrModule):
         elif PROJECT_TABLES and user_indices.dim() == 1 and _rows_path_ok(tables, hidden, user_indices.numel()) and not any(
                 getattr(t, "_ctr_sparse", None) is not None for t in tables):
             fn = _NeuralCFRowsFunction
-        out = fn.apply(user_indices.contiguous(), item_indices.contiguous(), self._err_flag(w.device),
-                       len(self.dnn_network), *tables, *dense)
+        n_hidden = len(self.dnn_network)
+        if fn is _NeuralCFProjFunction:
+            if getattr(self, "_ncf_counts", None) is None:
+                object.__setattr__(self, "_ncf_counts", ops.NcfCounts())
+            n_hidden = (n_hidden, torch.is_grad_enabled(), self._ncf_counts)
+        out = fn.apply(user_indices.contiguous(), item_indices.contiguous(), self._err_flag(w.device), n_hidden, *tables, *dense)
         self._raise_if_bad_index()
         return out
 

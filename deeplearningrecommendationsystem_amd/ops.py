@@ -643,11 +643,34 @@ def act_mask_bwd(g, y, act: int) -> None:
 # ---------------------------------------------------------------------------
 # NeuralCF with the first tower layer on the table rows (csrc/ncf_proj.hip)
 # ---------------------------------------------------------------------------
+class NcfCounts:
+    """the per-row sample counters of ``ctr_ncf_proj_fwd`` (one holder per model).  The C entry points want them all
+    zero at a training forward and leave them zero after the backward, so in the usual forward -> backward rhythm the
+    buffer is filled once, here.  ``take`` hands it out when it is known to be clean; while a forward's counts still
+    wait for their backward (two graphs alive at once), or after a training forward that never got one, a later
+    forward gets a freshly zeroed buffer of its own instead."""
+
+    def __init__(self):
+        self.buf, self.state = None, "clean"
+
+    def take(self, rows: int, device):
+        n = rows * _lib.CTR_NCF_PROJ_COUNT_STRIDE      # a line per counter (ctrhip.h)
+        if self.buf is None or self.buf.numel() < n or self.buf.device != device:
+            self.buf, self.state = torch.zeros(n, dtype=torch.int32, device=device), "clean"
+        if self.state == "dirty":            # a training forward whose graph was dropped without a backward
+            self.buf.zero_()
+            self.state = "clean"
+        if self.state == "clean":
+            self.state = "busy"
+            return self.buf, True
+        return torch.zeros(n, dtype=torch.int32, device=device), False
+
+
 class NcfProj:
     """one forward of ``ctr_ncf_proj_fwd`` and what its backward needs.  ``tables`` = (gmf_u, gmf_i, mlp_u, mlp_i),
     ``hidden`` = the four tower layers, ``proj`` = (w, b) of ``linear``, ``head`` = (w, b) of ``linear2``."""
 
-    def __init__(self, user_idx, item_idx, tables, hidden, proj, head, err_flag, training):
+    def __init__(self, user_idx, item_idx, tables, hidden, proj, head, err_flag, training, counts: "NcfCounts" = None):
         self.user_idx, self.item_idx = user_idx, item_idx
         self.tables, self.hidden, self.proj, self.head = tables, hidden, proj, head
         gmf_u, gmf_i, mlp_u, mlp_i = tables
@@ -660,9 +683,18 @@ class NcfProj:
         self.ys = [torch.empty((m + 1, layer.weight.shape[0]), dtype=torch.float32, device=dev) for layer in hidden[1:]]
         self.prob_buf = torch.empty((m + 1, 1), dtype=torch.float32, device=dev)
         self.prob = self.prob_buf[:m]
-        self.counts = torch.empty(rows, dtype=torch.int32, device=dev) if training else None
-        self.ranks = torch.empty(2 * (m + 1), dtype=torch.int32, device=dev)   # (written in inference too: no conditional store)
+        self._holder, self._owns = None, False
+        self.counts = self.ranks = None
+        if training:
+            self._holder = counts if counts is not None else NcfCounts()
+            self.counts, self._owns = self._holder.take(rows, dev)
+            self.ranks = torch.empty(2 * (m + 1), dtype=torch.int32, device=dev)
         self.err_flag, self.training = err_flag, training
+
+    def __del__(self):
+        # a training forward that never saw its backward leaves the counters dirty
+        if getattr(self, "_owns", False) and self._holder.state == "busy":
+            self._holder.state = "dirty"
 
     def _desc(self):
         gmf_u, gmf_i, mlp_u, mlp_i = self.tables
@@ -702,8 +734,10 @@ class NcfProj:
         return {
             # (rows, 64) tables read, (rows, 64) projected rows written; one 64 x 64 product per row
             "ncfp_prep": lambda: (rows * 512, 2 * rows * 64 * 64),
-            # ids, four 256-byte rows (cache-resident tables), saved activations + prob + ranks written; tower + head
-            "ncfp_fwd": lambda: (m * (16 + 4 * 256 + 4 * (32 + 16 + 8) + 4 + 8), 2 * m * (tower + 72 + 64)),
+            # ids, four 256-byte rows (cache-resident tables), saved activations + prob written; tower + head
+            # (+ in training, by the rank workgroups of the same launch: ids again, two returning atomics, an 8-byte record)
+            "ncfp_fwd": lambda: (m * (16 + 4 * 256 + 4 * (32 + 16 + 8) + 4 + ((16 + 8 + 8) if self.training else 0)),
+                                 2 * m * (tower + 72 + 64)),
             # ids, prob, gprob, ranks, two projected rows, saved activations read; gz0 row stored twice + two records
             "ncfp_bwd": lambda: (m * (16 + 16 + 2 * 256 + 4 * (32 + 16 + 8) + 2 * 256 + 32), 4 * m * tower + 2 * m * 8),
             # both buckets (row + record) and one partner row per slot read, (rows, 128) sums added
@@ -757,6 +791,9 @@ class NcfProj:
                 g.phases = phase
                 rc = rc or _timed(label, self._meta(label), fn, C.byref(d), C.byref(g), _lib.stream_ptr())
         _lib.check(rc, "ctr_ncf_proj_bwd")
+        if self._owns:
+            self._holder.state = "clean"     # (the call's last launch zeroed the counters)
+        self._owns = False
 
 
 # ---------------------------------------------------------------------------

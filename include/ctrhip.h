@@ -461,11 +461,16 @@ int ctr_act_mask_bwd(float* g, int64_t ldg, const float* y, int64_t ldy, int64_t
  * layers[0].y is not used (the first layer's output never exists per sample); layers[1..3].y are the saved
  * activations (m + 1, 32), (m + 1, 16), (m + 1, 8) the forward writes and the backward reads.  EVERY per-sample
  * buffer has one spare row behind the batch (prob: m + 1 elements; ranks: 2 (m + 1) int32): lanes without a sample
- * store there, so that no store of the kernels is conditional.
- * Caller-owned buffers the forward fills for the backward: ptab (num_users + num_items, 64), wfold (76 floats),
- * ranks (always), and with training != 0: counts (num_users + num_items int32).  Parameters must not change between the
- * forward and the backward (the backward re-reads tables and ptab). */
+ * store / read there, so that no store of the per-sample kernels is conditional.
+ * Caller-owned buffers the forward fills for the backward: ptab (num_users + num_items, 64), wfold (76 floats), and
+ * with training != 0: ranks and counts ((num_users + num_items) * CTR_NCF_PROJ_COUNT_STRIDE int32: a row's counter
+ * has a 64-byte line to itself, same-line atomics are served one after the other).  counts must be ALL ZERO when a training forward
+ * is enqueued (its first launch takes every sample's rank with a returning atomic on them); ctr_ncf_proj_bwd's last
+ * launch leaves them all zero again, so a caller that pairs every training forward with its backward zero-fills the
+ * buffer once.  Parameters must not change between the forward and the backward (the backward re-reads tables and
+ * ptab). */
 #define CTR_NCF_PROJ_MAX_ROWS 16384
+#define CTR_NCF_PROJ_COUNT_STRIDE 16   /* int32 between the counters of two table rows: one 64-byte line each */
 typedef struct ctr_ncf_proj {
   const int64_t* user_idx; int64_t user_stride;   /* ids of the batch, element strides */
   const int64_t* item_idx; int64_t item_stride;
