@@ -59,6 +59,25 @@ struct Ids {
   int64_t nu, ni;
 };
 
+// Ranks of the samples [lo, hi): a returning atomic per sample and id column on the row's counter, an 8-byte record out.
+// Run by workgroups `first` .. gridDim - 1 of a launch that has other work in its first workgroups (see struct Fwd).
+struct RankJob {
+  Ids ids;
+  int32_t* counts; int32_t* ranks;
+  int64_t lo, hi;
+  int first;
+};
+__device__ __forceinline__ void rank_role(const RankJob& R) {
+  const int64_t nb = (int64_t)gridDim.x - R.first;
+  for (int64_t s0 = R.lo + ((int64_t)blockIdx.x - R.first) * kThreads + threadIdx.x; s0 < R.hi; s0 += nb * kThreads) {
+    const int64_t u = R.ids.uidx[s0 * R.ids.ustride], i = R.ids.iidx[s0 * R.ids.istride];
+    int ru = -1, ri = -1;                      // an id outside its table has no slot (the per-sample part raises the flag)
+    if ((uint64_t)u < (uint64_t)R.ids.nu) ru = atomicAdd(R.counts + u * kCountStride, 1);
+    if ((uint64_t)i < (uint64_t)R.ids.ni) ri = atomicAdd(R.counts + (R.ids.nu + i) * kCountStride, 1);
+    *reinterpret_cast<int2*>(R.ranks + 2 * s0) = make_int2(ru, ri);
+  }
+}
+
 // ------------------------------------------------------------------ prep: projected tables + head fold
 struct Prep {
   const float* mlp_u; const float* mlp_i;      // (nu, 64), (ni, 64)
@@ -68,14 +87,19 @@ struct Prep {
   // head fold (ctr_fold_head_fwd's map for p = 64, n = 64, k = 8): wfold[0:72], wfold[72] = cfold
   const float* fold_u; const float* fold_w; int64_t fold_ldw; const float* fold_b; const float* fold_b2;
   float* wfold;
+  RankJob rank;                                // training: the first part of the batch's ranks, by workgroups rank.first ..
 };
 
 __global__ void __launch_bounds__(kThreads)
 ncfp_prep_kernel(const Prep A) {
+  if ((int)blockIdx.x >= A.rank.first) {
+    rank_role(A.rank);
+    return;
+  }
   const int lane = threadIdx.x & 63, q = lane >> 4, n = lane & 15;
   const int64_t wave = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
   const int64_t ublocks = (A.nu + 15) / 16, iblocks = (A.ni + 15) / 16;
-  if (blockIdx.x == gridDim.x - 1) {
+  if ((int)blockIdx.x == A.rank.first - 1) {
     // the folded head (ctr_fold_head_fwd's map): wfold[t < 64] = u[t]; wfold[64 + c] = sum_i W[i][c] u[64 + i] (column c
     // by the 32 threads t % 8 == c, two terms each, summed through LDS); wfold[72] = b . u[64:] + b2
     __shared__ float s_f[kThreads];
@@ -149,8 +173,9 @@ struct Fwd {
   // memory side (~30 ns each) and a wave's memory operations retire in order (profiles/r03_rank_atomics.txt).  The unit
   // of that serialisation is the line, not the address: with the 2625 counters packed (164 lines, 800 adds each) the
   // atomics alone took 23 us; every counter therefore has a line to itself (kCountStride int32 apart): 6 us.
-  int32_t* counts; int32_t* ranks;
-  int fwd_blocks;
+  // The batch's ranks are split over TWO launches: the first part beside the ~40 workgroups of the projection launch, the
+  // rest here -- each about as long as the work it runs beside.
+  RankJob rank;
 };
 
 // How the loops of this file are written (what the first version got wrong, found with cycle stamps, an ablation and
@@ -189,15 +214,8 @@ constexpr int kFwdStores = 5;            // y1 x 2, y2, y3, prob
 template <int DBG>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 ncfp_fwd_kernel(const Tower T, int64_t m, const Fwd F) {
-  if ((int)blockIdx.x >= F.fwd_blocks) {
-    const int64_t nb = (int64_t)gridDim.x - F.fwd_blocks;
-    for (int64_t s0 = ((int64_t)blockIdx.x - F.fwd_blocks) * kThreads + threadIdx.x; s0 < m; s0 += nb * kThreads) {
-      const int64_t u = F.ids.uidx[s0 * F.ids.ustride], i = F.ids.iidx[s0 * F.ids.istride];
-      int ru = -1, ri = -1;                    // an id outside its table has no slot (the per-sample part raises the flag)
-      if ((uint64_t)u < (uint64_t)F.ids.nu) ru = atomicAdd(F.counts + u * kCountStride, 1);
-      if ((uint64_t)i < (uint64_t)F.ids.ni) ri = atomicAdd(F.counts + (F.ids.nu + i) * kCountStride, 1);
-      *reinterpret_cast<int2*>(F.ranks + 2 * s0) = make_int2(ru, ri);
-    }
+  if ((int)blockIdx.x >= F.rank.first) {
+    rank_role(F.rank);
     return;
   }
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -209,7 +227,7 @@ ncfp_fwd_kernel(const Tower T, int64_t m, const Fwd F) {
   float* stage = s_hw + 80 + wave * kFwdStage;        // this wave's rows: [table][row][chunk ^ row] x 16 bytes
   const uint32_t stage_addr = lds_addr(stage);
   const int64_t groups = (m + 15) / 16;
-  const int64_t wave0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6, nwaves = ((int64_t)F.fwd_blocks * kThreads) >> 6;
+  const int64_t wave0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6, nwaves = ((int64_t)F.rank.first * kThreads) >> 6;
   const uint32_t nu = (uint32_t)F.ids.nu, ni = (uint32_t)F.ids.ni;
   const float* tabs[4] = {F.ptab, F.ptab + F.ids.nu * kN0, F.gmf_u, F.gmf_i};
   // stage 1: the two ids of this lane's sample (sample n of the group, the same in its four lanes)
@@ -1157,9 +1175,16 @@ extern "C" int ctr_ncf_proj_fwd(const ctr_ncf_proj_t* d, void* stream) {
   const int64_t nu = d->num_users, ni = d->num_items;
   const int64_t pwaves = ctr_ceil_div(nu, 16) + ctr_ceil_div(ni, 16);
   const Ids ids{d->user_idx, d->user_stride, d->item_idx, d->item_stride, nu, ni};
+  // training: the samples' ranks, part in this launch, part in the next (RankJob)
+  static const int rank_split = [] { const char* e = getenv("CTR_NCFP_RANK_SPLIT"); return e ? atoi(e) : 50; }();   // per cent (sweep: dev/r03_rank_split.sh)
+  const int64_t m_first = d->training ? d->batch * rank_split / 100 / kThreads * kThreads : 0;
+  const int proj_blocks = (int)ctr_ceil_div(pwaves, kWaves) + 1;
+  int64_t rank_a = ctr_ceil_div(m_first, kThreads);
+  if (rank_a > 256) rank_a = 256;
   const Prep P{d->mlp_user, d->mlp_item, d->layers[0].w, d->layers[0].k, d->layers[0].b, d->ptab, nu, ni,
-               d->head_w, d->proj_w, d->ld_proj_w, d->proj_b, d->head_b, d->wfold};
-  if (phases & 1) hipLaunchKernelGGL(ncfp_prep_kernel, dim3((unsigned)(ctr_ceil_div(pwaves, kWaves) + 1)), dim3(kThreads), 0, st, P);
+               d->head_w, d->proj_w, d->ld_proj_w, d->proj_b, d->head_b, d->wfold,
+               RankJob{ids, d->counts, d->ranks, 0, m_first, proj_blocks}};
+  if (phases & 1) hipLaunchKernelGGL(ncfp_prep_kernel, dim3((unsigned)(proj_blocks + rank_a)), dim3(kThreads), 0, st, P);
   rc = ctr_launch_status();
   if (rc != CTR_OK || d->batch == 0 || !(phases & 2)) return rc;
   const int64_t groups = ctr_ceil_div(d->batch, 16);
@@ -1168,10 +1193,10 @@ extern "C" int ctr_ncf_proj_fwd(const ctr_ncf_proj_t* d, void* stream) {
   static const int fwd_wgs = [] { const char* e = getenv("CTR_NCFP_FWD_WGS"); return e ? atoi(e) : 256; }();
   if (grid > fwd_wgs) grid = fwd_wgs;
   // rank workgroups (training): one sample per thread up to a chip's worth of them, behind the per-sample ones
-  int64_t rank_blocks = d->training ? ctr_ceil_div(d->batch, kThreads) : 0;
+  int64_t rank_blocks = d->training ? ctr_ceil_div(d->batch - m_first, kThreads) : 0;
   if (rank_blocks > 256) rank_blocks = 256;
   const Fwd F{ids, d->ptab, d->gmf_user, d->gmf_item, d->wfold, d->prob, d->ldprob, d->head_act, d->err_flag,
-              d->training ? d->counts : nullptr, d->ranks, (int)grid};
+              RankJob{ids, d->counts, d->ranks, m_first, d->training ? d->batch : m_first, (int)grid}};
   static const int dbg = [] { const char* e = getenv("CTR_NCFP_DBG"); return e ? atoi(e) : 0; }();
   constexpr size_t fwd_lds = sizeof(float) * (kWFloats + kBFloats + 80 + kWaves * kFwdStage);
   switch (dbg) {
