@@ -1,14 +1,16 @@
 // Row-sharded embedding tables (one process per GPU, owner(row) = row % world,
 // local row = row / world): bucket a batch of global ids by owning rank before the
-// RCCL all-to-all.  Two passes over the ids (HBM-bound, 8 B read + 16 B written per id):
-//   count : per-workgroup LDS histogram of owners -> counts[world]; ids outside [0, vocab) are counted in
-//           counts[world] (the host reads the counts anyway to size the exchange and raises IndexError) and
-//           travel as row 0 of rank 0
-//   place : slot = start[owner] + cursor[owner]++  (the order inside a bucket is not fixed;
-//           `perm` / `inv` record it so the rows can be put back in batch order)
+// RCCL all-to-all.  Two passes over the ids (HBM-bound, 8 B read + 16 B written per id), each workgroup on its own
+// contiguous slice of the batch:
+//   count : LDS histogram of the slice's owners -> hist[workgroup][0..world] in the scratch; ids outside [0, vocab) are
+//           counted in [world] (the host reads the counts anyway to size the exchange and raises IndexError) and travel
+//           as row 0 of rank 0
+//   place : slot = (ids of lower owners) + (this owner's ids in the slices in front) + rank inside the slice, from the
+//           histograms and an LDS counter -- no global atomic (the order inside a bucket is the batch order of the
+//           slices, inside a 256-id pass it is not fixed; `perm` / `inv` record it)
 // outputs: send[slot] = local row as int32 (what goes on the wire: half the bytes of the int64 ids),
-// perm[i] = slot, inv[slot] = i.  counts / cursor are zeroed by a kernel of their own: no hipMemsetAsync in
-// the library (hipGraph note), so the bucketing can sit inside a captured step.
+// perm[i] = slot, inv[slot] = i.  No hipMemsetAsync in the library (hipGraph note): every scratch word a
+// launch reads is written by the launch before it, so the bucketing can sit inside a captured step.
 #include "ctr_common.h"
 
 namespace {
@@ -16,17 +18,21 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kMaxWorld = 64;
 
-__global__ void zero_counters_kernel(int64_t* __restrict__ counts, int64_t* __restrict__ cursor, int world) {
-  if ((int)threadIdx.x <= world) counts[threadIdx.x] = 0;   // counts has world + 1 slots (the last: bad ids)
-  if ((int)threadIdx.x < world) cursor[threadIdx.x] = 0;
-}
+// Both passes give workgroup w the contiguous slice [w*chunk, (w+1)*chunk) of the ids, so the placement needs no global
+// atomic: `count` stores the slice's histogram hist[w][0..world] (plain stores; [world] = ids outside the table), `place`
+// sums the histograms of the workgroups in front of it.  (Round 2 bumped one global cursor per owner and workgroup pass:
+// n / 256 returning atomics per owner on ONE 64-byte line, served one after the other at ~30 ns -- 0.4 ms for the 3.3 M
+// ids of a DIN batch, most of what a fresh id tensor's exchange plan cost.)
+constexpr int kMaxGrid = 256;
 
 __global__ void __launch_bounds__(kBlock)
-owner_count_kernel(const int64_t* __restrict__ ids, int64_t n, int world, int64_t vocab, int64_t* __restrict__ counts) {
+owner_count_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t chunk, int world, int64_t vocab,
+                   int64_t* __restrict__ hist) {
   __shared__ int s_cnt[kMaxWorld + 1];
   if (threadIdx.x <= kMaxWorld) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     int64_t r = ids[i];
     if (r < 0 || r >= vocab) {
       atomicAdd(&s_cnt[kMaxWorld], 1);
@@ -35,34 +41,61 @@ owner_count_kernel(const int64_t* __restrict__ ids, int64_t n, int world, int64_
     atomicAdd(&s_cnt[(int)(r % world)], 1);
   }
   __syncthreads();
-  if (threadIdx.x < world && s_cnt[threadIdx.x])
-    atomicAdd(reinterpret_cast<unsigned long long*>(counts + threadIdx.x), (unsigned long long)s_cnt[threadIdx.x]);
-  if (threadIdx.x == 0 && s_cnt[kMaxWorld])
-    atomicAdd(reinterpret_cast<unsigned long long*>(counts + world), (unsigned long long)s_cnt[kMaxWorld]);
+  if ((int)threadIdx.x <= world)
+    hist[(int64_t)blockIdx.x * (world + 1) + threadIdx.x] = s_cnt[(int)threadIdx.x < world ? threadIdx.x : kMaxWorld];
 }
 
-__global__ void __launch_bounds__(kBlock)
-owner_place_kernel(const int64_t* __restrict__ ids, int64_t n, int world, int64_t vocab,
-                   const int64_t* __restrict__ counts, int64_t* __restrict__ cursor, int32_t* __restrict__ send,
-                   int64_t* __restrict__ perm, int64_t* __restrict__ inv) {
-  __shared__ int64_t s_start[kMaxWorld];
-  __shared__ int s_cnt[kMaxWorld];
-  __shared__ int64_t s_base[kMaxWorld];
+// s_first[o] = first slot of this workgroup's ids of owner o; totals[o] = ids of owner o in the whole batch
+__device__ __forceinline__ void slice_bases(const int64_t* __restrict__ hist, int world, int64_t* s_first, int64_t* s_total,
+                                            int64_t* s_before) {
+  // thread (o, part): owner o, workgroups part, part + parts, ... ; then a tree over the parts in LDS
+  const int o = threadIdx.x % (kMaxWorld + 1), part = threadIdx.x / (kMaxWorld + 1), parts = kBlock / (kMaxWorld + 1);
+  __shared__ int64_t s_t[kBlock], s_b[kBlock];
+  int64_t tot = 0, bef = 0;
+  if (o <= world && part < parts)
+    for (int w = part; w < (int)gridDim.x; w += parts) {
+      const int64_t c = hist[(int64_t)w * (world + 1) + o];
+      tot += c;
+      if (w < (int)blockIdx.x) bef += c;
+    }
+  s_t[threadIdx.x] = tot;
+  s_b[threadIdx.x] = bef;
+  __syncthreads();
+  if (part == 0 && o <= world) {
+    for (int p2 = 1; p2 < parts; ++p2) {
+      tot += s_t[p2 * (kMaxWorld + 1) + o];
+      bef += s_b[p2 * (kMaxWorld + 1) + o];
+    }
+    s_total[o] = tot;
+    s_before[o] = bef;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     int64_t acc = 0;
     for (int w = 0; w < world; ++w) {
-      s_start[w] = acc;
-      acc += counts[w];
+      s_first[w] = acc + s_before[w];
+      acc += s_total[w];
     }
   }
-  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += (int64_t)gridDim.x * blockDim.x) {
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(kBlock)
+owner_place_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t chunk, int world, int64_t vocab,
+                   const int64_t* __restrict__ hist, int64_t* __restrict__ counts, int32_t* __restrict__ send,
+                   int64_t* __restrict__ perm, int64_t* __restrict__ inv) {
+  __shared__ int64_t s_first[kMaxWorld], s_total[kMaxWorld + 1], s_before[kMaxWorld + 1];
+  __shared__ int s_cnt[kMaxWorld];
+  slice_bases(hist, world, s_first, s_total, s_before);
+  if (blockIdx.x == 0 && (int)threadIdx.x <= world) counts[threadIdx.x] = s_total[threadIdx.x];
+  const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  for (int64_t i0 = lo; i0 < hi; i0 += blockDim.x) {
     if (threadIdx.x < kMaxWorld) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    // one global cursor bump per (workgroup pass, owner), ranks inside it from LDS
     const int64_t i = i0 + threadIdx.x;
     int owner = 0, rank = 0;
     int64_t local = 0;
-    if (i < n) {
+    if (i < hi) {
       int64_t r = ids[i];
       if (r < 0 || r >= vocab) r = 0;
       owner = (int)(r % world);
@@ -70,16 +103,14 @@ owner_place_kernel(const int64_t* __restrict__ ids, int64_t n, int world, int64_
       rank = atomicAdd(&s_cnt[owner], 1);
     }
     __syncthreads();
-    if (threadIdx.x < world && s_cnt[threadIdx.x])
-      s_base[threadIdx.x] = (int64_t)atomicAdd(reinterpret_cast<unsigned long long*>(cursor + threadIdx.x),
-                                               (unsigned long long)s_cnt[threadIdx.x]);
-    __syncthreads();
-    if (i < n) {
-      const int64_t slot = s_start[owner] + s_base[owner] + rank;
+    if (i < hi) {
+      const int64_t slot = s_first[owner] + rank;
       send[slot] = (int32_t)local;
       perm[i] = slot;
       inv[slot] = i;
     }
+    __syncthreads();
+    if ((int)threadIdx.x < world) s_first[threadIdx.x] += s_cnt[threadIdx.x];
     __syncthreads();
   }
 }
@@ -90,46 +121,50 @@ owner_place_kernel(const int64_t* __restrict__ ids, int64_t n, int world, int64_
 // not placed (perm points at the bucket's last slot so that later gathers stay in bounds) and the overflow is reported
 // in state[0] -- the caller then falls back to the exact layout.  Unused slots carry -1 on the wire.
 __global__ void __launch_bounds__(kBlock)
-padded_init_kernel(int32_t* __restrict__ send, int64_t* __restrict__ inv, int64_t slots, int64_t n,
-                   int64_t* __restrict__ cursor, int world) {
-  if (blockIdx.x == 0 && (int)threadIdx.x <= world) cursor[threadIdx.x] = 0;   // cursor[world]: ids outside the table
+padded_init_kernel(int32_t* __restrict__ send, int64_t* __restrict__ inv, int64_t slots, int64_t n) {
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < slots; j += (int64_t)gridDim.x * blockDim.x) {
     send[j] = -1;
     inv[j] = n > 0 ? j % n : 0;   // an unused slot sends SOME row of the caller's gradient: the owner masks it out
   }
 }
 
+// same slices and histograms as the exact layout (owner_count_kernel): slot = owner*cap + ids of that owner in front
 __global__ void __launch_bounds__(kBlock)
-padded_place_kernel(const int64_t* __restrict__ ids, int64_t n, int world, int64_t vocab, int64_t cap,
-                    int64_t* __restrict__ cursor, int32_t* __restrict__ send, int64_t* __restrict__ perm,
-                    int64_t* __restrict__ inv) {
-  __shared__ int s_cnt[kMaxWorld + 1];
-  __shared__ int64_t s_base[kMaxWorld];
-  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += (int64_t)gridDim.x * blockDim.x) {
-    if (threadIdx.x <= kMaxWorld) s_cnt[threadIdx.x] = 0;
+padded_place_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t chunk, int world, int64_t vocab, int64_t cap,
+                    const int64_t* __restrict__ hist, int32_t* __restrict__ send, int64_t* __restrict__ perm,
+                    int64_t* __restrict__ inv, int64_t* __restrict__ state) {
+  __shared__ int64_t s_first[kMaxWorld], s_total[kMaxWorld + 1], s_before[kMaxWorld + 1];
+  __shared__ int s_cnt[kMaxWorld];
+  slice_bases(hist, world, s_first, s_total, s_before);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // state = {a bucket overflowed, ids outside the table, n, -n}: one MAX all-reduce tells every rank whether ANY rank
+    // must fall back / raise and whether the ranks passed different id counts (max n != -max(-n))
+    int64_t over = 0;
+    for (int w = 0; w < world; ++w) over |= s_total[w] > cap ? 1 : 0;
+    state[0] = over;
+    state[1] = s_total[world];
+    state[2] = n;
+    state[3] = -n;
+  }
+  if ((int)threadIdx.x < world) s_first[threadIdx.x] = s_before[threadIdx.x];   // position inside the owner's bucket
+  __syncthreads();
+  const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+  for (int64_t i0 = lo; i0 < hi; i0 += blockDim.x) {
+    if (threadIdx.x < kMaxWorld) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const int64_t i = i0 + threadIdx.x;
     int owner = 0, rank = 0;
     int64_t local = 0;
-    if (i < n) {
+    if (i < hi) {
       int64_t r = ids[i];
-      if (r < 0 || r >= vocab) {
-        atomicAdd(&s_cnt[kMaxWorld], 1);
-        r = 0;
-      }
+      if (r < 0 || r >= vocab) r = 0;
       owner = (int)(r % world);
       local = r / world;
       rank = atomicAdd(&s_cnt[owner], 1);
     }
     __syncthreads();
-    if (threadIdx.x < world && s_cnt[threadIdx.x])
-      s_base[threadIdx.x] = (int64_t)atomicAdd(reinterpret_cast<unsigned long long*>(cursor + threadIdx.x),
-                                               (unsigned long long)s_cnt[threadIdx.x]);
-    if (threadIdx.x == 0 && s_cnt[kMaxWorld])
-      atomicAdd(reinterpret_cast<unsigned long long*>(cursor + world), (unsigned long long)s_cnt[kMaxWorld]);
-    __syncthreads();
-    if (i < n) {
-      const int64_t at = s_base[owner] + rank;
+    if (i < hi) {
+      const int64_t at = s_first[owner] + rank;
       const int64_t slot = (int64_t)owner * cap + (at < cap ? at : cap - 1);
       perm[i] = slot;
       if (at < cap) {
@@ -138,20 +173,9 @@ padded_place_kernel(const int64_t* __restrict__ ids, int64_t n, int world, int64
       }
     }
     __syncthreads();
+    if ((int)threadIdx.x < world) s_first[threadIdx.x] += s_cnt[threadIdx.x];
+    __syncthreads();
   }
-}
-
-// state = {a bucket overflowed, ids outside the table, n, -n}: one MAX all-reduce tells every rank whether ANY rank must
-// fall back / raise and whether the ranks passed different id counts (max n != -max(-n))
-__global__ void padded_state_kernel(const int64_t* __restrict__ cursor, int world, int64_t cap, int64_t n,
-                                    int64_t* __restrict__ state) {
-  if (threadIdx.x != 0) return;
-  int64_t over = 0;
-  for (int w = 0; w < world; ++w) over |= cursor[w] > cap ? 1 : 0;
-  state[0] = over;
-  state[1] = cursor[world];
-  state[2] = n;
-  state[3] = -n;
 }
 
 // what the owner makes of the received slots: rows to gather / scatter (an unused slot reads and "updates" -- by an
@@ -191,6 +215,14 @@ rows_zero_kernel(float* __restrict__ table, int64_t ld, int dim, const int64_t* 
 
 }  // namespace
 
+static inline void slices(int64_t n, int* grid, int64_t* chunk) {
+  int64_t g = ctr_ceil_div(n, 8 * kBlock);           // at least eight passes of a workgroup per slice
+  if (g > kMaxGrid) g = kMaxGrid;
+  if (g < 1) g = 1;
+  *grid = (int)g;
+  *chunk = ctr_ceil_div(n, g);
+}
+
 extern "C" int ctr_shard_bucket_padded(const int64_t* ids, int64_t n, int world, int64_t vocab, int64_t cap,
                                        int64_t* cursor, int32_t* send, int64_t* perm, int64_t* inv, int64_t* state,
                                        void* stream) {
@@ -199,14 +231,14 @@ extern "C" int ctr_shard_bucket_padded(const int64_t* ids, int64_t n, int world,
   CTR_REQUIRE(vocab / world < (1ll << 31), CTR_ELIMIT);
   hipStream_t st = (hipStream_t)stream;
   const int64_t slots = (int64_t)world * cap;
-  hipLaunchKernelGGL(padded_init_kernel, dim3(ctr_stream_grid(slots, kBlock)), dim3(kBlock), 0, st, send, inv, slots, n,
-                     cursor, world);
-  if (n > 0) {
-    CTR_REQUIRE(ids && perm, CTR_EINVAL);
-    hipLaunchKernelGGL(padded_place_kernel, dim3(ctr_stream_grid(n, kBlock)), dim3(kBlock), 0, st, ids, n, world, vocab,
-                       cap, cursor, send, perm, inv);
-  }
-  hipLaunchKernelGGL(padded_state_kernel, dim3(1), dim3(64), 0, st, cursor, world, cap, n, state);
+  int grid;
+  int64_t chunk;
+  slices(n, &grid, &chunk);
+  hipLaunchKernelGGL(padded_init_kernel, dim3(ctr_stream_grid(slots, kBlock)), dim3(kBlock), 0, st, send, inv, slots, n);
+  CTR_REQUIRE(n == 0 || (ids && perm), CTR_EINVAL);
+  hipLaunchKernelGGL(owner_count_kernel, dim3(grid), dim3(kBlock), 0, st, ids, n, chunk, world, vocab, cursor);
+  hipLaunchKernelGGL(padded_place_kernel, dim3(grid), dim3(kBlock), 0, st, ids, n, chunk, world, vocab, cap, cursor, send,
+                     perm, inv, state);
   return ctr_launch_status();
 }
 
@@ -239,13 +271,13 @@ extern "C" int ctr_shard_bucket(const int64_t* ids, int64_t n, int world, int64_
                                 int64_t* cursor, int32_t* send, int64_t* perm, int64_t* inv, void* stream) {
   CTR_REQUIRE(n >= 0 && world >= 1 && world <= kMaxWorld && counts && cursor && vocab > 0, CTR_EINVAL);
   CTR_REQUIRE(vocab / world < (1ll << 31), CTR_ELIMIT);  // local rows travel as int32
+  CTR_REQUIRE(n == 0 || (ids && send && perm && inv), CTR_EINVAL);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(zero_counters_kernel, dim3(1), dim3(kMaxWorld + 64), 0, st, counts, cursor, world);
-  if (n == 0) return ctr_launch_status();
-  CTR_REQUIRE(ids && send && perm && inv, CTR_EINVAL);
-  const int grid = ctr_stream_grid(n, kBlock);
-  hipLaunchKernelGGL(owner_count_kernel, dim3(grid), dim3(kBlock), 0, st, ids, n, world, vocab, counts);
-  hipLaunchKernelGGL(owner_place_kernel, dim3(grid), dim3(kBlock), 0, st, ids, n, world, vocab, counts, cursor, send, perm,
-                     inv);
+  int grid;
+  int64_t chunk;
+  slices(n, &grid, &chunk);
+  hipLaunchKernelGGL(owner_count_kernel, dim3(grid), dim3(kBlock), 0, st, ids, n, chunk, world, vocab, cursor);
+  hipLaunchKernelGGL(owner_place_kernel, dim3(grid), dim3(kBlock), 0, st, ids, n, chunk, world, vocab, cursor, counts, send,
+                     perm, inv);
   return ctr_launch_status();
 }

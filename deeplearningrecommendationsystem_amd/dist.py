@@ -139,7 +139,7 @@ class HipShardBackend:
         n = ids.numel()
         dev = ids.device
         counts = torch.empty(world + 1, dtype=torch.int64, device=dev)
-        cursor = torch.empty(world, dtype=torch.int64, device=dev)
+        cursor = torch.empty(256 * (world + 1), dtype=torch.int64, device=dev)      # CTR_SHARD_SCRATCH_INT64 (ctrhip.h)
         send = torch.empty(n, dtype=torch.int32, device=dev)
         perm = torch.empty(n, dtype=torch.int64, device=dev)
         inv = torch.empty(n, dtype=torch.int64, device=dev)
@@ -157,7 +157,7 @@ class HipShardBackend:
         _lib.require_device(ids)
         n, dev = ids.numel(), ids.device
         state = torch.empty(4, dtype=torch.int64, device=dev)
-        cursor = torch.empty(world + 1, dtype=torch.int64, device=dev)
+        cursor = torch.empty(256 * (world + 1), dtype=torch.int64, device=dev)      # CTR_SHARD_SCRATCH_INT64 (ctrhip.h)
         send = torch.empty(world * cap, dtype=torch.int32, device=dev)
         perm = torch.empty(n, dtype=torch.int64, device=dev)
         inv = torch.empty(world * cap, dtype=torch.int64, device=dev)

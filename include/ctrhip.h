@@ -515,15 +515,17 @@ int ctr_mlp_bwd(const float* x, int64_t ldx, int64_t m, const ctr_mlp_layer_t* l
  *   counts[w]  = ids owned by rank w, w < world; counts[world] = ids outside [0, vocab)  (world + 1 int64, written)
  *   send[slot] = local row as int32 (the wire format), buckets back to back in rank order
  *   perm[i]    = slot of id i;  inv[slot] = i           (order inside a bucket is not fixed)
- * cursor: world int64 of scratch.  Ids outside [0, vocab) travel as row 0 and are counted.
+ * cursor: CTR_SHARD_SCRATCH_INT64(world) int64 of scratch (per-workgroup histograms; no global atomics are used).
+ * Ids outside [0, vocab) travel as row 0 and are counted.
  * ---------------------------------------------------------------------- */
+#define CTR_SHARD_SCRATCH_INT64(world) (256 * ((world) + 1))
 int ctr_shard_bucket(const int64_t* ids, int64_t n, int world, int64_t vocab, int64_t* counts, int64_t* cursor,
                      int32_t* send, int64_t* perm, int64_t* inv, void* stream);
 /* The capacity-bounded layout of the same bucketing: bucket w is slots [w*cap, (w+1)*cap) of `send` / `inv`
  * (world*cap entries each) whatever the counts are, so the all-to-all has equal, host-known splits and a fresh id
  * tensor needs no host read before its ids travel.  send[slot] = local row or -1 (unused); perm[i] = slot of id i;
- * inv[slot] = i (an unused slot names some id of the batch: its row is masked out by the owner).  cursor: world + 1
- * int64 of scratch (left holding the per-owner counts and the number of ids outside [0, vocab)).
+ * inv[slot] = i (an unused slot names some id of the batch: its row is masked out by the owner).  cursor:
+ * CTR_SHARD_SCRATCH_INT64(world) int64 of scratch.
  * state (4 int64, written): {1 if a bucket received more than cap ids -- those ids are NOT placed, the caller must
  * fall back to ctr_shard_bucket --, ids outside [0, vocab), n, -n}: MAX-all-reduced by the caller. */
 int ctr_shard_bucket_padded(const int64_t* ids, int64_t n, int world, int64_t vocab, int64_t cap, int64_t* cursor,
