@@ -15,12 +15,13 @@ import torch  # noqa: F401  (maps libamdhip64 first, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CTRHIP_LIB", os.path.join(_HERE, "libctrhip.so"))  # env override: A/B builds
-ABI_VERSION = 32
+ABI_VERSION = 33
 DIN_TRIPLE, DIN_PAIR, DIN_H = 0, 1, 2  # layouts of the DIN attention operand (include/ctrhip.h)
 
 CTR_MAX_FIELDS = 32
 CTR_NCF_PROJ_MAX_ROWS = 16384
 CTR_NCF_PROJ_COUNT_STRIDE = 16
+CTR_ROWS1_MAX_ROWS = 32768
 FIELD_ID_I64, FIELD_ID_F32, FIELD_BAG, FIELD_DENSE, FIELD_PROD_I64 = range(5)
 ACT_NONE, ACT_RELU, ACT_SIGMOID = range(3)
 
@@ -175,6 +176,7 @@ SIGNATURES = {
     "ctr_shard_recv_rows": (_i, [_p, _l, _l, _p, _p, _p, _p]),
     "ctr_rows_zero": (_i, [_p, _l, _l, _i, _p, _l, _p]),
     "ctr_topk_rows": (_i, [_p, _l, _l, _l, _l, _i, _p, _p, _p]),
+    "ctr_rows1_scatter": (_i, [_p, _l, _i, _i, _p, _l, _p, _l, _l, _p, _l, _p, _l, _p]),
     "ctr_fold_head_fwd": (_i, [_p, _i, _p, _l, _p, _p, _i, _i, _p, _p, _p]),
     "ctr_fold_head_bwd": (_i, [_p, _i, _p, _l, _p, _i, _i, _p, _p, _p, _p, _l, _p, _p, _p]),
     "ctr_bce_fwd": (_i, [_p, _l, _p, _l, _l, _p, _p, _l, _p, _p, _p]),

@@ -1,7 +1,7 @@
 // ABI bookkeeping entry points of libctrhip.
 #include "ctr_common.h"
 
-extern "C" int ctr_version(void) { return 32; }
+extern "C" int ctr_version(void) { return 33; }
 
 extern "C" const char* ctr_target_arch(void) { return "gfx950"; }
 

@@ -9,6 +9,7 @@ write straight into the consumer's operand.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -851,11 +852,41 @@ def fm_wide_fwd(emb, nvec, dim, x, user1, item1, wide_w, wide_b, out, err_flag=N
     _lib.check(rc, "ctr_fm_wide_fwd")
 
 
+ROWS1_IN_LDS = os.environ.get("CTR_ROWS1_LDS", "1") != "0"   # 0: the interaction kernels' own per-sample atomics (A/B)
+
+
+def _rows1_small(x, guser1, gitem1) -> bool:
+    """the (V, 1) first-order gradients of SMALL tables leave ``fm_wide_bwd``: per-sample 4-byte atomics on a few dozen cache
+    lines queue up at the memory side (csrc/rows_sum.hip, ctr_rows1_scatter).  Measured (profiles/r03_rows1_ab.txt): logistic
+    regression 66.5 -> 58.0 us per step, Wide & Deep / AFM unchanged; under ``ffm_fused_bwd`` the atomics only cost 5 us and
+    the extra launch 10, so FFM keeps them in the kernel."""
+    if not ROWS1_IN_LDS or x.shape[0] < 4096 or (guser1 is None and gitem1 is None):
+        return False
+    rows = (guser1.shape[0] if guser1 is not None else 1) + (gitem1.shape[0] if gitem1 is not None else 1)
+    return rows <= _lib.CTR_ROWS1_MAX_ROWS
+
+
+def rows1_scatter(x, g, prob, guser1, gitem1) -> None:
+    """guser1[x[:, 0]] += v, gitem1[x[:, 1]] += v, v = g (* p (1 - p) when ``prob`` is given)"""
+    x, g = _mat(x, "x"), _mat(g, "g")
+    batch = x.shape[0]
+    nu = guser1.shape[0] if guser1 is not None else 1
+    ni = gitem1.shape[0] if gitem1 is not None else 1
+    rc = _timed("rows1_scatter", lambda: (batch * (8 + 4 + (4 if prob is not None else 0)) + 8 * (nu + ni), 2 * batch),
+                _lib.load().ctr_rows1_scatter, x.data_ptr(), _ld(x), USER_COL, ITEM_COL, g.data_ptr(), _ld(g),
+                _lib.ptr(prob), _ld(prob) if prob is not None else 0, batch, _lib.ptr(guser1), nu, _lib.ptr(gitem1), ni,
+                _lib.stream_ptr())
+    _lib.check(rc, "ctr_rows1_scatter")
+
+
 def fm_wide_bwd(emb, nvec, dim, x, user1, item1, wide_w, wide_b, gout, guser1, gitem1, gwide_w, gwide_b, gemb,
                 accumulate: bool) -> None:
     emb, gout = _mat(emb, "emb"), _mat(gout, "gout")
     batch = emb.shape[0]
     ws = _scratch(emb.device)
+    if _rows1_small(x, guser1, gitem1):
+        rows1_scatter(x, gout, None, guser1, gitem1)
+        guser1 = gitem1 = None
     rc = _timed("fm_wide_bwd", lambda: (4 * batch * ((2 + int(accumulate)) * nvec * dim + 45 + 5),
                                         4 * batch * nvec * dim),
                 _lib.load().ctr_fm_wide_bwd, emb.data_ptr(), _ld(emb), batch, nvec, dim,

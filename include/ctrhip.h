@@ -539,6 +539,17 @@ int ctr_shard_recv_rows(const int32_t* recv, int64_t slots, int64_t local_rows, 
  * persistent dense shard-gradient buffer instead of zero-filling the whole shard */
 int ctr_rows_zero(float* table, int64_t ld, int64_t rows, int dim, const int64_t* idx, int64_t n, void* stream);
 
+/* Gradient of two (V, 1) first-order tables indexed by the float id columns `user_col` / `item_col` of the (B, ldx)
+ * feature matrix (model/ffm.py:19-26 `user` / `item` embeddings, lr.py / widedeep.py / deepfm.py first-order terms):
+ * guser1[x[b, user_col]] += v_b, gitem1[x[b, item_col]] += v_b with v_b = g[b*ldg], or g[b*ldg] * p (1 - p) with
+ * p = prob[b*ldp] when prob is not NULL (the dlogit of a sigmoid head).  Ids outside their table are skipped.  Either
+ * gradient may be NULL.  Small tables only (num_users + num_items <= CTR_ROWS1_MAX_ROWS: they are summed in LDS per
+ * workgroup; CTR_ELIMIT beyond -- the interaction kernels' own first-order atomics are the path for large tables). */
+#define CTR_ROWS1_MAX_ROWS 32768
+int ctr_rows1_scatter(const float* x, int64_t ldx, int user_col, int item_col, const float* g, int64_t ldg,
+                      const float* prob, int64_t ldp, int64_t batch, float* guser1, int64_t num_users, float* gitem1,
+                      int64_t num_items, void* stream);
+
 /* ------------------------------------------------------------------------
  * Ranking step of recommendation() (model/mf.py:28-35, neuralcf.py:61-72, pnn.py:133-143, din.py:55-66: torch.topk
  * over one user's candidate scores): for each of `rows` rows of n scores (element (r, j) at

@@ -1025,6 +1025,32 @@ def test_topk_rows_ranks_like_torch_with_ties_by_index(rows, n, k):
         ops.topk_rows(scores.to(DEV), n + 1)
 
 
+@pytest.mark.parametrize("batch,nu,ni,with_prob", [(65536, 943, 1682, True), (5000, 7, 3, False), (4096, 16000, 16000, True),
+                                                    (70001, 300, 1, False)])
+def test_rows1_scatter_sums_first_order_gradients_in_lds(batch, nu, ni, with_prob):
+    """csrc/rows_sum.hip: the (V, 1) first-order gradients of small tables, against a float64 scatter on the host"""
+    from deeplearningrecommendationsystem_amd import ops
+    g = torch.Generator().manual_seed(batch + nu)
+    x = torch.rand(batch, 45, generator=g)
+    x[:, 0] = torch.randint(0, nu, (batch,), generator=g).float()
+    x[:, 1] = torch.randint(0, ni, (batch,), generator=g).float()
+    x[5, 0], x[6, 1] = nu + 3.0, -1.0                                   # ids outside their table add nothing
+    gv = torch.randn(batch, 1, generator=g)
+    prob = torch.rand(batch, 1, generator=g) if with_prob else None
+    v = (gv * prob * (1 - prob) if with_prob else gv).double().view(-1)
+    u, it = x[:, 0].long(), x[:, 1].long()
+    want_u = torch.zeros(nu, dtype=torch.float64).index_put_((u[(u >= 0) & (u < nu)],), v[(u >= 0) & (u < nu)], accumulate=True)
+    want_i = torch.zeros(ni, dtype=torch.float64).index_put_((it[(it >= 0) & (it < ni)],), v[(it >= 0) & (it < ni)], accumulate=True)
+    gu, gi = torch.full((nu, 1), 0.5, device=DEV), torch.full((ni, 1), -0.25, device=DEV)        # (+=)
+    ops.rows1_scatter(x.to(DEV), gv.to(DEV), prob.to(DEV) if with_prob else None, gu, gi)
+    scale = max(1.0, (batch / min(nu, ni)) ** 0.5)
+    torch.testing.assert_close(gu.cpu().view(-1), (want_u + 0.5).float(), rtol=1e-5, atol=2e-6 * scale)
+    torch.testing.assert_close(gi.cpu().view(-1), (want_i - 0.25).float(), rtol=1e-5, atol=2e-6 * scale)
+    only = torch.zeros((nu, 1), device=DEV)
+    ops.rows1_scatter(x.to(DEV), gv.to(DEV), prob.to(DEV) if with_prob else None, only, None)   # one table alone
+    torch.testing.assert_close(only.cpu().view(-1), want_u.float(), rtol=1e-5, atol=2e-6 * scale)
+
+
 def test_bce_loss_matches_torch():
     from deeplearningrecommendationsystem_amd.loss import BCELoss
     g = torch.Generator().manual_seed(2)
