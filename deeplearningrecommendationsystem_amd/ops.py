@@ -765,6 +765,12 @@ class NcfProj:
     def backward(self, gprob: torch.Tensor, grads: dict, zero: Optional[torch.Tensor]) -> None:
         """``grads[id(param)]``: where each parameter's gradient accumulates; ``zero``: the flat buffer behind them,
         cleared by the call's first launch"""
+        if getattr(self, "_spent", False):
+            # the call's last launch clears the sample counters for the next forward: a second backward over the same
+            # forward would bucket with empty counters
+            raise RuntimeError("NeuralCF backward consumes what its forward saved: run the forward again before a second "
+                               "backward (retain_graph is not supported)")
+        self._spent = True
         gmf_u, gmf_i, mlp_u, mlp_i = self.tables
         d = self._desc()
         g = _lib.NcfProjGrad()
