@@ -124,3 +124,26 @@ def test_kernel_profiler_mixed_shapes_and_roofline_bounds():
     assert e["bound"] == "l2" and e["peak"] == bench.L2_PEAK_GBS and abs(e["dram_gbs"] - 4e7 / 50e-6 / 1e9) < 1e-6
     # a 3 us launch moving 2 MB: latency
     assert bench.roofline_entry("x", k["x"])["bound"] == "latency"
+
+
+def test_ncf_counts_holder_hands_out_a_clean_buffer_or_a_private_one():
+    """ops.NcfCounts (the sample counters of ctr_ncf_proj_fwd): clean -> handed out; busy -> a private zeroed buffer for
+    the second forward; dirty (a training forward without a backward) -> zero-filled before it is handed out again"""
+    import torch
+    from deeplearningrecommendationsystem_amd import _lib, ops
+    h = ops.NcfCounts()
+    cpu = torch.device("cpu")
+    a, owns_a = h.take(10, cpu)
+    assert owns_a and a.numel() == 10 * _lib.CTR_NCF_PROJ_COUNT_STRIDE and int(a.abs().sum()) == 0 and h.state == "busy"
+    b, owns_b = h.take(10, cpu)                      # a second forward before the first one's backward
+    assert not owns_b and b.data_ptr() != a.data_ptr() and int(b.abs().sum()) == 0 and h.state == "busy"
+    h.state = "clean"                                # the owner's backward ran (its last launch zeroes the counters)
+    c, owns_c = h.take(10, cpu)
+    assert owns_c and c.data_ptr() == a.data_ptr()
+    c[3] = 7                                         # ... a forward that never got its backward leaves counts behind
+    h.state = "dirty"
+    d, owns_d = h.take(10, cpu)
+    assert owns_d and d.data_ptr() == a.data_ptr() and int(d.abs().sum()) == 0
+    h.state = "clean"
+    e, _ = h.take(20, cpu)                           # more table rows: a new buffer
+    assert e.numel() == 20 * _lib.CTR_NCF_PROJ_COUNT_STRIDE and int(e.abs().sum()) == 0
