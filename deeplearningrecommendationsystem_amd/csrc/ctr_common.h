@@ -154,6 +154,10 @@ int ctr_skinny_dw(const float* x, int64_t ldx, const float* y, int64_t ldy, cons
                   float* gb, int64_t m, int n, int k, int act, float* workspace, int64_t workspace_floats,
                   hipStream_t st);
 // gemm_dlds.hip: forward GEMM with direct global->LDS operand loads
+// wide layers on a long batch: 256 x 256 macro tile, one workgroup per CU (gemm_wide.hip)
+bool ctr_gemm_wide_ok(const float* x, int64_t ldx, const float* w, int64_t ldw, int64_t m, int n, int k);
+int ctr_gemm_wide_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y, int64_t ldy,
+                      int64_t m, int n, int k, int act, hipStream_t st);
 bool ctr_gemm_dlds_ok(const float* x, int64_t ldx, const float* w, int64_t ldw, int64_t m, int n, int k);
 int ctr_gemm_dlds_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, const float* res,
                       int64_t ldr, float* y, int64_t ldy, int64_t m, int n, int k, int act, hipStream_t st);

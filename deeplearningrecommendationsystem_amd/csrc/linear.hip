@@ -464,6 +464,9 @@ extern "C" int ctr_linear_fwd(const float* x, int64_t ldx, const float* w, int64
   }
   if (n == 1 && ctr_n1_supported(k))
     return ctr_n1_fwd(x, ldx, w, bias, residual, ldr, y, ldy, m, k, act, (hipStream_t)stream);
+  // wide layer, long batch: the 256 x 256 macro tile (gemm_wide.hip)
+  if (!residual && ctr_gemm_wide_ok(x, ldx, w, ldw, m, n, k))
+    return ctr_gemm_wide_fwd(x, ldx, w, ldw, bias, y, ldy, m, n, k, act, (hipStream_t)stream);
   // K >= 16: operands stream global -> LDS directly (gemm_dlds.hip: 1.1-1.6x the tile kernel)
   if (ctr_gemm_dlds_ok(x, ldx, w, ldw, m, n, k))
     return ctr_gemm_dlds_fwd(x, ldx, w, ldw, bias, residual, ldr, y, ldy, m, n, k, act, (hipStream_t)stream);

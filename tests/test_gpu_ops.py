@@ -230,6 +230,7 @@ LINEAR_SHAPES = [
     # direct-to-LDS kernels (gemm_dlds*.hip): sizes that are not multiples of the 16-float step / 4-float
     # chunk on either side (shifted last chunks, fragment masks), both dW orientations, split launches
     (4200, 641, 641), (4160, 256, 161), (4100, 385, 193),   # widths just above a multiple of 128: main + tail launches
+    (4096, 256, 256), (4500, 512, 416), (4100, 256, 272), (8000, 768, 48),   # 256 x 256 macro tile (gemm_wide.hip): n % 256 == 0, k % 16 == 0, k >= 256
     (4500, 130, 131), (4100, 97, 35), (4200, 33, 103), (4097, 19, 30), (5000, 200, 17), (4099, 161, 289), (3000, 256, 15), (3000, 6, 5), (2000, 40, 4),
     # single-unit layers over a long batch: four rows in flight per lane group (linear_n1.hip)
     (262200, 1, 64), (270001, 1, 20), (262144, 1, 3),
