@@ -116,29 +116,44 @@ gemm_wide_fwd_kernel(const WideArgs a) {
       __builtin_amdgcn_s_barrier();
       f32x4 fa[4][2], fb[4][2];
       const uint32_t sb = base0 + (uint32_t)stage * (kStageFloats * 4);
+      // the fragments of the step's first half (kk 0..3 | 8..11), then the next stage's requests, then the second half:
+      // one wave per SIMD has nobody to hide its LDS latency behind, so the second half is waited for only after the
+      // first 64 MFMAs (LDS reads return in order: lgkmcnt(8) = the first eight have landed)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        fa[i][0] = lds_read128(sb + aoff[i][0]);
+        fb[i][0] = lds_read128(sb + boff[i][0]);
+      }
 #pragma unroll
-        for (int v = 0; v < 2; ++v) {
-          fa[i][v] = lds_read128(sb + aoff[i][v]);
-          fb[i][v] = lds_read128(sb + boff[i][v]);
-        }
+      for (int i = 0; i < 4; ++i) {
+        fa[i][1] = lds_read128(sb + aoff[i][1]);
+        fb[i][1] = lds_read128(sb + boff[i][1]);
+      }
       int refill = stage + 2;
       refill = refill >= kStages ? refill - kStages : refill;
       if (ks + 2 < nk) issue(refill, ks + 2);
-      // every fragment register passes through the wait, so no MFMA can be scheduled above it
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]),
-                     "+v"(fa[3][0]), "+v"(fa[3][1]));
-      asm volatile("" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1]),
-                   "+v"(fb[3][0]), "+v"(fb[3][1]));
+      // every fragment register passes through its wait, so no MFMA that uses it can be scheduled above it
+      asm volatile("s_waitcnt lgkmcnt(8)"
+                   : "+v"(fa[0][0]), "+v"(fa[1][0]), "+v"(fa[2][0]), "+v"(fa[3][0]), "+v"(fb[0][0]), "+v"(fb[1][0]),
+                     "+v"(fb[2][0]), "+v"(fb[3][0]));
 #pragma unroll
-      for (int t = 0; t < 8; ++t)
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t >> 2][t & 3], fb[j][t >> 2][t & 3], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][0][t], fb[j][0][t], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);     // (the wait below must stay behind these MFMAs: nothing else ties it there)
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(fa[0][1]), "+v"(fa[1][1]), "+v"(fa[2][1]), "+v"(fa[3][1]), "+v"(fb[0][1]), "+v"(fb[1][1]),
+                     "+v"(fb[2][1]), "+v"(fb[3][1]));
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][1][t], fb[j][1][t], acc[i][j], 0, 0, 0);
       stage = stage + 1 == kStages ? 0 : stage + 1;
     }
     // C/D map of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
