@@ -8,8 +8,9 @@
 // instructions for the same MFMA work (91 against 104 TF).  Here a step is 16 ds_read_b128 for 128 MFMAs per wave.
 //
 // Taken by ctr_linear_fwd when it applies (ctr_gemm_wide_ok): n a multiple of 256, k a multiple of 16 and >= 256, aligned
-// operands, a batch of at least 4096 rows, no residual.  First version: 95.5 TF on 65536 x 256 x 512 (gemm_dlds.hip 91,
-// hipBLASLt 106.7); what it still lacks is in profiles/r03_gemm_wide.txt.  Operands stream global -> LDS with the same 16-byte-chunk
+// operands, a batch of at least 4096 rows, no residual -- and CTR_GEMM_WIDE=1: this first version reaches 96.3 TF on
+// 65536 x 256 x 512 in the microbenchmark (gemm_dlds.hip 90.5, hipBLASLt 106.7) but loses inside the models' steps;
+// profiles/r03_gemm_wide.txt has both measurements and what it still lacks.  Operands stream global -> LDS with the same 16-byte-chunk
 // layout, swizzle and ring of three stages as gemm_dlds.hip.
 #include "ctr_common.h"
 
@@ -95,7 +96,10 @@ gemm_wide_fwd_kernel(const WideArgs a) {
   }
   const uint32_t base0 = lds_addr(lds);
 
-  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+  // a workgroup walks the column tiles of ITS row tiles back to back: the 256 x k operand rows are then re-read from this
+  // XCD's L2 (neighbouring workgroups sit on different XCDs: splitting a row tile's columns over them fetched X from
+  // HBM once per column tile -- 65536 x 512 x 416 inside DeepFM-26: 318 us against 278 for the 128-wide kernel)
+  for (int64_t tile = (int64_t)blockIdx.x * ntiles; tile < tiles; tile = (tile + 1) % ntiles ? tile + 1 : tile + 1 + ((int64_t)gridDim.x - 1) * ntiles) {
     const int64_t i0 = (tile / ntiles) * kTM, j0 = (int64_t)(tile % ntiles) * kTN;
     floatx16 acc[4][4];
 #pragma unroll
@@ -181,7 +185,9 @@ gemm_wide_fwd_kernel(const WideArgs a) {
 }  // namespace
 
 bool ctr_gemm_wide_ok(const float* x, int64_t ldx, const float* w, int64_t ldw, int64_t m, int n, int k) {
-  static const int enabled = [] { const char* e = getenv("CTR_GEMM_WIDE"); return e ? atoi(e) : 1; }();
+  // OFF by default: faster than gemm_dlds.hip in the microbenchmark (operands served by the Infinity Cache) but slower
+  // inside the steps, where X was just written by another kernel and comes from HBM (profiles/r03_gemm_wide.txt)
+  static const int enabled = [] { const char* e = getenv("CTR_GEMM_WIDE"); return e ? atoi(e) : 0; }();
   // (a deep contraction only: the epilogue -- 256 dword stores per wave at one wave per SIMD -- is what a short one is
   // made of: 65536 x 256 x 128 67 us against 58 us for gemm_dlds.hip, x 512 180 against 189: profiles/r03_gemm_wide.txt)
   return enabled && m >= 4096 && n % kTN == 0 && k % kBK == 0 && k >= 256 && ctr_aligned16(x) && ctr_aligned16(w) &&
@@ -191,8 +197,8 @@ bool ctr_gemm_wide_ok(const float* x, int64_t ldx, const float* w, int64_t ldw, 
 int ctr_gemm_wide_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, float* y, int64_t ldy,
                       int64_t m, int n, int k, int act, hipStream_t st) {
   const WideArgs a{x, ldx, w, ldw, bias, y, ldy, m, n, k, act};
-  const int64_t tiles = ctr_ceil_div(m, kTM) * (n / kTN);
-  const int64_t grid = tiles < 256 ? tiles : 256;
+  const int64_t mtiles = ctr_ceil_div(m, kTM);
+  const int64_t grid = mtiles < 256 ? mtiles : 256;          // one row tile (all its column tiles) per workgroup and round
   constexpr int lds_bytes = kStages * kStageFloats * (int)sizeof(float);   // 96 KB
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_wide_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           lds_bytes) != hipSuccess)

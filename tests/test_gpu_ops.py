@@ -270,6 +270,28 @@ def test_linear_backward(ops, m, n, k, act):
     torch.testing.assert_close(gb.cpu(), bd.grad.float(), rtol=1e-5, atol=2e-6 * scale)
 
 
+@pytest.mark.parametrize("m,n,k,act", [(4096, 256, 256, 1), (4500, 512, 416, 0), (4100, 256, 272, 2), (70000, 256, 512, 1)])
+def test_linear_forward_wide_macro_tile(m, n, k, act):
+    """csrc/gemm_wide.hip (256 x 256 macro tile; opt-in: CTR_GEMM_WIDE=1) in a process of its own, against float64"""
+    import subprocess
+    import sys
+    code = f"""
+import torch
+from deeplearningrecommendationsystem_amd import ops
+g = torch.Generator().manual_seed({m + n + k})
+x, w, b = torch.randn({m}, {k}, generator=g), torch.randn({n}, {k}, generator=g) / {k} ** 0.5, torch.randn({n}, generator=g)
+y = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda(), {act}).cpu()
+ref = x.double() @ w.double().T + b.double()
+ref = [ref, torch.relu(ref), torch.sigmoid(ref)][{act}]
+torch.testing.assert_close(y, ref.float(), rtol=1e-5, atol=4e-6)
+print("ok")
+"""
+    env = dict(os.environ, CTR_GEMM_WIDE="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
 def test_linear_strided_views_residual_and_accumulate(ops):
     g = torch.Generator().manual_seed(9)
     m, n, k = 200, 24, 40
